@@ -1,0 +1,508 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REAL reference and records inputs/outputs.
+
+TEST INFRASTRUCTURE ONLY.  Runs in the build container, where the reference is
+mounted read-only at /root/reference; it never runs on the GPU box.  It imports
+the reference package from /root/reference/src (one empty in-process stand-in
+for the off-path, not-installed ``pyvista`` plotting module),
+calls the reference's own functions on seeded inputs and writes the results as
+small ``.npz`` fixtures under tests/golden/.  No reference source is copied.
+
+    python oracle/gen_golden.py [--only G1,G3,...] [--jobs 8]
+
+Fixtures:
+  G1 lattices, G2 quantiser tables, G3 exhaustive nearest-tile tables,
+  G4 spatial analyzer runs (config 1), G5 transition analyzer runs,
+  G6 ingest edge cases, G7 per-direction weight rows, G8 dense transition
+  frames (bucket quirk exercised), G9 operator-level edge cases.
+"""
+
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import os
+import sys
+import tempfile
+import types
+from multiprocessing import Pool
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent.parent
+REF_SRC = Path("/root/reference/src")
+OUT = REPO / "tests" / "golden"
+
+
+def _import_reference():
+    if not REF_SRC.exists():
+        sys.exit("reference not mounted at /root/reference; nothing to do")
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.dont_write_bytecode = True
+    sys.modules.setdefault("pyvista", types.ModuleType("pyvista"))
+    sys.path.insert(0, str(REF_SRC))
+    import viewport_entropy_toolkit as vt  # noqa: F401  (the reference)
+    return vt
+
+
+def _load_synth():
+    p = REPO / "viewport-entropy-toolkit_amd" / "viewport_entropy_toolkit" / "_synthetic.py"
+    spec = importlib.util.spec_from_file_location("_vet_synth", p)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def vec_arr(vs):
+    return np.array([[v.x, v.y, v.z] for v in vs], dtype=np.float64)
+
+
+# ----------------------------------------------------------------------------
+def g1_lattices(vt):
+    from viewport_entropy_toolkit.utilities import generate_fibonacci_lattice
+    out = {}
+    for tc in (1, 2, 3, 20, 50, 100, 200, 250, 500, 1000):
+        out[f"tc{tc}"] = vec_arr(generate_fibonacci_lattice(tc))
+    np.savez_compressed(OUT / "g1_lattices.npz", **out)
+    print("G1", {k: v.shape for k, v in out.items()})
+
+
+# ----------------------------------------------------------------------------
+def _axis_tables(vt, W, H):
+    """px -> lon and py -> lat exactly as process_viewport_data +
+    format_trajectory_data produce them (rounding + the <=-180 / <=-90 remap)."""
+    import pandas as pd
+    from viewport_entropy_toolkit.utilities import format_trajectory_data, pixel_to_spherical
+    from viewport_entropy_toolkit import Point
+    # longitude axis: px = 0..W at py = H/2 ; latitude axis: py = 0..H at px = W/2
+    rows = []
+    for px in range(W + 1):
+        rp = pixel_to_spherical(Point(px, H // 2), W, H)
+        rows.append((rp.lon, rp.lat))
+    for py in range(H + 1):
+        rp = pixel_to_spherical(Point(W // 2, py), W, H)
+        rows.append((rp.lon, rp.lat))
+    # format_trajectory_data is O(T^2) in its time search; feed it in chunks of
+    # distinct times so the quadratic term stays small.
+    lon_out, lat_out = [], []
+    CH = 400
+    for s in range(0, len(rows), CH):
+        part = rows[s:s + CH]
+        df = pd.DataFrame({
+            "time": np.arange(len(part)) * 0.1,
+            "lon": [float(r[0]) for r in part],
+            "lat": [float(r[1]) for r in part],
+        })
+        pts, _ = format_trajectory_data([("u", df)])
+        assert len(pts) == len(part)
+        for rp in pts["u"]:
+            lon_out.append(rp.lon)
+            lat_out.append(rp.lat)
+    lon_axis = np.array(lon_out[:W + 1], dtype=np.float64)
+    lat_axis = np.array(lat_out[W + 1:], dtype=np.float64)
+    return lon_axis, lat_axis
+
+
+def g2_quantiser(vt):
+    from viewport_entropy_toolkit import Vector
+    out = {}
+    for (W, H) in ((100, 200), (3840, 1920), (6, 4)):
+        lon_axis, lat_axis = _axis_tables(vt, W, H)
+        out[f"lon_{W}x{H}"] = lon_axis
+        out[f"lat_{W}x{H}"] = lat_axis
+    # full (lon,lat) -> Vector grid at the default size, [H+1][W+1][3]
+    W, H = 100, 200
+    lon_axis, lat_axis = out["lon_100x200"], out["lat_100x200"]
+    grid = np.empty((H + 1, W + 1, 3), dtype=np.float64)
+    for py in range(H + 1):
+        for px in range(W + 1):
+            v = Vector.from_spherical(float(lon_axis[px]), float(lat_axis[py]))
+            grid[py, px] = (v.x, v.y, v.z)
+    out["vec_100x200"] = grid
+    # a sparse sample of the big grid
+    rng = np.random.default_rng(7)
+    W, H = 3840, 1920
+    pxs = rng.integers(0, W + 1, 4000)
+    pys = rng.integers(0, H + 1, 4000)
+    big = np.empty((4000, 3))
+    for i, (px, py) in enumerate(zip(pxs, pys)):
+        v = Vector.from_spherical(float(out["lon_3840x1920"][px]), float(out["lat_3840x1920"][py]))
+        big[i] = (v.x, v.y, v.z)
+    out["big_px"], out["big_py"], out["big_vec"] = pxs, pys, big
+    np.savez_compressed(OUT / "g2_quantiser.npz", **out)
+    print("G2 done")
+
+
+# ----------------------------------------------------------------------------
+_G3 = {}
+
+
+def _g3_init():
+    vt = _import_reference()
+    from viewport_entropy_toolkit.utilities import generate_fibonacci_lattice
+    _G3["vt"] = vt
+    _G3["gen"] = generate_fibonacci_lattice
+
+
+def _g3_work(args):
+    tc, dirs = args
+    from viewport_entropy_toolkit.utilities import find_nearest_tile
+    from viewport_entropy_toolkit import Vector
+    L = _G3["gen"](tc)
+    return [find_nearest_tile(Vector(*d), L) for d in dirs]
+
+
+def g3_nearest(vt, jobs):
+    g2 = np.load(OUT / "g2_quantiser.npz")
+    grid = g2["vec_100x200"]                      # [201][101][3]
+    flat = grid.reshape(-1, 3)
+    uniq, inv = np.unique(flat, axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    print("G3 unique directions:", len(uniq), "of", len(flat))
+    out = {}
+    with Pool(jobs, initializer=_g3_init) as pool:
+        for tc in (20, 50, 100, 200, 250, 500, 1000):
+            chunks = np.array_split(uniq, jobs * 8)
+            res = pool.map(_g3_work, [(tc, [tuple(map(float, d)) for d in c]) for c in chunks])
+            near = np.concatenate([np.asarray(r, dtype=np.int16) for r in res])
+            out[f"tc{tc}"] = near[inv].reshape(grid.shape[0], grid.shape[1])
+            print("G3 tc", tc, "done", flush=True)
+    np.savez_compressed(OUT / "g3_nearest.npz", **out)
+
+
+# ----------------------------------------------------------------------------
+def _write_csvs(d, times, mus, mvs, names):
+    import pandas as pd
+    for nm, t, a, b in zip(names, times, mus, mvs):
+        pd.DataFrame({"time": t, "2dmu": a, "2dmv": b, "extra": 1}).to_csv(d / f"{nm}.csv", index=False)
+
+
+def _config1_inputs(synth, U=8, T=300, seed=1234):
+    names = [f"user{u:03d}" for u in range(U)]
+    ts, mus, mvs = [], [], []
+    for u in range(U):
+        t, a, b = synth.random_walk_user(T, seed + u)
+        ts.append(t), mus.append(a), mvs.append(b)
+    return names, ts, mus, mvs
+
+
+def _tw_dense(tile_weights, lattice):
+    idx = {v: i for i, v in enumerate(lattice)}
+    row = np.zeros(len(lattice))
+    touched = np.zeros(len(lattice), dtype=bool)
+    for v, w in tile_weights.items():
+        row[idx[v]] = w
+        touched[idx[v]] = True
+    return row, touched
+
+
+def g4_spatial(vt, synth):
+    from viewport_entropy_toolkit import SpatialEntropyAnalyzer, AnalyzerConfig
+    from viewport_entropy_toolkit.config import EntropyConfig
+    names, ts, mus, mvs = _config1_inputs(synth)
+    variants = [
+        ("w_tc50", dict(tile_counts=[50]), dict()),
+        ("w_tc50_100_200", dict(tile_counts=[50, 100, 200]), dict()),
+        ("u_tc50", dict(tile_counts=[50]), dict(use_weight_distribution=False)),
+        ("u_tc20_50", dict(tile_counts=[20, 50]), dict(use_weight_distribution=False)),
+        ("w_tc50_p15", dict(tile_counts=[50]), dict(power_factor=1.5)),
+        ("w_tc50_fov90", dict(tile_counts=[50]), dict(fov_angle=90.0)),
+        ("w_tc100_fov200_p05", dict(tile_counts=[100]), dict(fov_angle=200.0, power_factor=0.5)),
+    ]
+    out = {"time_in": np.array(ts), "mu_in": np.array(mus), "mv_in": np.array(mvs)}
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        d = td / "video"
+        d.mkdir()
+        _write_csvs(d, ts, mus, mvs, names)
+        os.chdir(td)
+        for tag, acfg, ecfg in variants:
+            cfg = AnalyzerConfig(output_dir=td / "out", entropy_config=EntropyConfig(**ecfg), **acfg)
+            an = SpatialEntropyAnalyzer(cfg)
+            an.process_directory(d)
+            res = an.compute_entropy()
+            cols = [c for c in an._data_cache["vectors"].columns if c != "time"]
+            lat0 = an._fibonacci_vectors[cfg.tile_counts[0]]
+            out[f"{tag}__columns"] = np.array(cols)
+            out[f"{tag}__time"] = res["time"].to_numpy(dtype=np.float64)
+            out[f"{tag}__entropy"] = res["entropy"].to_numpy(dtype=np.float64)
+            asg = np.full((len(res), len(cols)), -1, dtype=np.int32)
+            for i, a in enumerate(res["tile_assignments"]):
+                for j, c in enumerate(cols):
+                    if c in a:
+                        asg[i, j] = a[c]
+            out[f"{tag}__assign"] = asg
+            fr = [0, 150, 299]
+            tw = np.stack([_tw_dense(res["tile_weights"][i], lat0)[0] for i in fr])
+            out[f"{tag}__weights_frames"] = np.array(fr)
+            out[f"{tag}__weights"] = tw
+            print("G4", tag, float(res["entropy"].mean()), flush=True)
+    np.savez_compressed(OUT / "g4_spatial.npz", **out)
+
+
+def g5_transition(vt, synth):
+    from viewport_entropy_toolkit import TransitionEntropyAnalyzer, AnalyzerConfig
+    names, ts, mus, mvs = _config1_inputs(synth)
+    out = {"time_in": np.array(ts), "mu_in": np.array(mus), "mv_in": np.array(mvs)}
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        d = td / "video"
+        d.mkdir()
+        _write_csvs(d, ts, mus, mvs, names)
+        os.chdir(td)
+        for tag, tcs in (("tc200", [200]), ("tc20_50", [20, 50])):
+            cfg = AnalyzerConfig(output_dir=td / "out", tile_counts=tcs)
+            an = TransitionEntropyAnalyzer(cfg)
+            an.process_directory(d)
+            res = an.compute_entropy()
+            cols = [c for c in an._data_cache["vectors"].columns if c != "time"]
+            lat0 = an._fibonacci_vectors[tcs[0]]
+            idx = {v: i for i, v in enumerate(lat0)}
+            out[f"{tag}__columns"] = np.array(cols)
+            out[f"{tag}__time"] = res["time"].to_numpy(dtype=np.float64)
+            out[f"{tag}__entropy"] = res["entropy"].to_numpy(dtype=np.float64)
+            pairs = np.full((len(res), len(cols), 2), -1, dtype=np.int32)
+            src = np.zeros((len(res), len(lat0)), dtype=np.int32)
+            for i, (a, w) in enumerate(zip(res["tile_assignments"], res["tile_weights"])):
+                for j, c in enumerate(cols):
+                    if c in a:
+                        pairs[i, j] = a[c]
+                for v, n in w.items():
+                    src[i, idx[v]] = n
+            out[f"{tag}__pairs"] = pairs
+            out[f"{tag}__srccount"] = src
+            print("G5", tag, float(np.nanmean(res["entropy"])), flush=True)
+    np.savez_compressed(OUT / "g5_transition.npz", **out)
+
+
+# ----------------------------------------------------------------------------
+def g6_ingest(vt):
+    """Ingest edge cases: -180/-90 remap, duplicate rounded time (last wins),
+    NaN row drop, unsorted + disjoint times, absent users, mu/mv == 1.0."""
+    import pandas as pd
+    from viewport_entropy_toolkit import SpatialEntropyAnalyzer, TransitionEntropyAnalyzer, AnalyzerConfig
+    from viewport_entropy_toolkit.config import EntropyConfig
+    a = pd.DataFrame({
+        "time": [10.0, 10.04, 10.1, 10.31, 10.2, 10.5, 10.52],
+        "2dmu": [0.0, 0.004, 0.5, 1.0, 0.25, np.nan, 0.75],
+        "2dmv": [0.5, 0.5, 1.0, 0.0, 0.999, 0.5, 0.3],
+    })
+    b = pd.DataFrame({
+        "time": [3.3, 3.0, 3.1, 3.9, 4.4],
+        "2dmu": [0.1, 0.2, 0.995, 0.4, 0.61],
+        "2dmv": [0.1, 0.2, 0.005, 0.4, 0.77],
+    })
+    c = pd.DataFrame({
+        "time": [0.0, 0.1, 0.2, 0.3, 0.5, 7.0],
+        "2dmu": [0.33, 0.34, 0.35, 0.36, 0.37, 0.38],
+        "2dmv": [0.66, 0.65, 0.64, 0.63, 0.62, 0.61],
+    })
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        d = td / "edge"
+        d.mkdir()
+        for nm, df in (("ua", a), ("ub", b), ("uc", c)):
+            df.to_csv(d / f"{nm}.csv", index=False)
+            out[f"in_{nm}"] = df.to_numpy(dtype=np.float64)
+        os.chdir(td)
+        for tag, ecfg in (("w", {}), ("u", dict(use_weight_distribution=False))):
+            cfg = AnalyzerConfig(output_dir=td / "out", tile_counts=[50, 20], entropy_config=EntropyConfig(**ecfg))
+            an = SpatialEntropyAnalyzer(cfg)
+            an.process_directory(d)
+            res = an.compute_entropy()
+            cols = [c_ for c_ in an._data_cache["vectors"].columns if c_ != "time"]
+            pts, vecs = an._data_cache["points"], an._data_cache["vectors"]
+            T = len(vecs)
+            lonlat = np.full((T, len(cols), 2), np.nan)
+            xyz = np.full((T, len(cols), 3), np.nan)
+            for j, cname in enumerate(cols):
+                for i in range(T):
+                    rp, v = pts[cname][i], vecs[cname][i]
+                    if rp is not None:
+                        lonlat[i, j] = (rp.lon, rp.lat)
+                        xyz[i, j] = (v.x, v.y, v.z)
+            asg = np.full((T, len(cols)), -1, dtype=np.int32)
+            for i, amap in enumerate(res["tile_assignments"]):
+                for j, cname in enumerate(cols):
+                    if cname in amap:
+                        asg[i, j] = amap[cname]
+            out[f"{tag}__columns"] = np.array(cols)
+            out[f"{tag}__time"] = vecs["time"].to_numpy(dtype=np.float64)
+            out[f"{tag}__lonlat"] = lonlat
+            out[f"{tag}__xyz"] = xyz
+            out[f"{tag}__entropy"] = res["entropy"].to_numpy(dtype=np.float64)
+            out[f"{tag}__assign"] = asg
+        # transition on the same edge data: frames with no common user raise
+        cfg = AnalyzerConfig(output_dir=td / "out", tile_counts=[50])
+        an = TransitionEntropyAnalyzer(cfg)
+        an.process_directory(d)
+        try:
+            an.compute_entropy()
+            out["t__raised"] = np.array("none")
+        except Exception as e:  # noqa: BLE001
+            out["t__raised"] = np.array(type(e).__name__)
+    np.savez_compressed(OUT / "g6_ingest.npz", **out)
+    print("G6 done; transition on edge data raised:", out["t__raised"])
+
+
+# ----------------------------------------------------------------------------
+def g7_weight_rows(vt):
+    from viewport_entropy_toolkit import Vector
+    from viewport_entropy_toolkit.utilities import (generate_fibonacci_lattice, calculate_tile_weights,
+                                                    find_nearest_tile, EntropyConfig)
+    g2 = np.load(OUT / "g2_quantiser.npz")
+    grid = g2["vec_100x200"]
+    rng = np.random.default_rng(11)
+    pys = rng.integers(0, 201, 48)
+    pxs = rng.integers(0, 101, 48)
+    # force a few special directions: (1,0,0) == tile N, (-1,0,0) mirror tie, poles
+    pys[:4] = (100, 100, 0, 200)
+    pxs[:4] = (50, 0, 10, 10)
+    out = {"px": pxs, "py": pys}
+    for tag, tc, ecfg in (("tc500", 500, {}), ("tc50_p15_fov90", 50, dict(power_factor=1.5, fov_angle=90.0)),
+                          ("tc100_fov360", 100, dict(fov_angle=360.0, power_factor=3.0))):
+        L = generate_fibonacci_lattice(tc)
+        idx = {v: i for i, v in enumerate(L)}
+        cfg = EntropyConfig(**ecfg)
+        rows = np.zeros((len(pxs), len(L)))
+        near = np.zeros(len(pxs), dtype=np.int32)
+        for i, (px, py) in enumerate(zip(pxs, pys)):
+            v = Vector(*map(float, grid[py, px]))
+            for tv, w in calculate_tile_weights(v, L, cfg).items():
+                rows[i, idx[tv]] = w
+            near[i] = find_nearest_tile(v, L)
+        out[f"{tag}__rows"] = rows
+        out[f"{tag}__nearest"] = near
+    np.savez_compressed(OUT / "g7_weight_rows.npz", **out)
+    print("G7 done")
+
+
+# ----------------------------------------------------------------------------
+def g8_dense_transition(vt, synth):
+    """Many users on few tiles so that a source tile has several users and the
+    reference's int-key/Vector-key bucket behaviour decides the result."""
+    from viewport_entropy_toolkit import Vector
+    from viewport_entropy_toolkit.utilities import (generate_fibonacci_lattice, compute_transition_entropy,
+                                                    compute_spatial_entropy, EntropyConfig)
+    g2 = np.load(OUT / "g2_quantiser.npz")
+    grid = g2["vec_100x200"]
+    U, T = 40, 41
+    rng = np.random.default_rng(5)
+    # clustered walk: everybody near the equator front, small steps
+    px = np.clip(50 + np.cumsum(rng.integers(-3, 4, (T, U)), axis=0) + rng.integers(-8, 9, (1, U)), 0, 100)
+    py = np.clip(100 + np.cumsum(rng.integers(-3, 4, (T, U)), axis=0) + rng.integers(-10, 11, (1, U)), 0, 200)
+    present = rng.random((T, U)) > 0.15
+    present[:, 0] = True
+    out = {"px": px, "py": py, "present": present}
+    cfg = EntropyConfig()
+    for tc in (20, 50):
+        L = generate_fibonacci_lattice(tc)
+        idx = {v: i for i, v in enumerate(L)}
+        ent = np.zeros(T - 1)
+        pairs = np.full((T - 1, U, 2), -1, dtype=np.int32)
+        src = np.zeros((T - 1, len(L)), dtype=np.int32)
+        prev = None
+        for t in range(T):
+            cur = {f"u{u:02d}": Vector(*map(float, grid[py[t, u], px[t, u]])) for u in range(U) if present[t, u]}
+            if prev is not None:
+                e, w, a = compute_transition_entropy(prev, cur, L, cfg, 120)
+                ent[t - 1] = e
+                for u in range(U):
+                    k = f"u{u:02d}"
+                    if k in a:
+                        pairs[t - 1, u] = a[k]
+                for v, n in w.items():
+                    src[t - 1, idx[v]] = n
+            prev = cur
+        out[f"tc{tc}__entropy"] = ent
+        out[f"tc{tc}__pairs"] = pairs
+        out[f"tc{tc}__srccount"] = src
+        # the same frames through the spatial operator, unweighted + weighted
+        for tag, ec in (("u", EntropyConfig(use_weight_distribution=False)), ("w", EntropyConfig())):
+            se = np.zeros(T)
+            for t in range(T):
+                cur = {f"u{u:02d}": Vector(*map(float, grid[py[t, u], px[t, u]])) for u in range(U) if present[t, u]}
+                se[t] = compute_spatial_entropy(cur, L, ec)[0]
+            out[f"tc{tc}__spatial_{tag}"] = se
+        print("G8 tc", tc, "mean", ent.mean(), flush=True)
+    np.savez_compressed(OUT / "g8_dense_transition.npz", **out)
+
+
+# ----------------------------------------------------------------------------
+def g9_operator_edges(vt):
+    from viewport_entropy_toolkit import Vector
+    from viewport_entropy_toolkit.utilities import (generate_fibonacci_lattice, compute_transition_entropy,
+                                                    compute_spatial_entropy, EntropyConfig)
+    import warnings
+    warnings.simplefilter("ignore")
+    L = generate_fibonacci_lattice(50)
+    v = Vector.from_spherical(12.6, -3.6)
+    v2 = Vector.from_spherical(-100.8, 45.0)
+    out = {"v": np.array([v.x, v.y, v.z]), "v2": np.array([v2.x, v2.y, v2.z])}
+    # single user, unweighted -> nan ; weighted fine
+    out["single_unweighted"] = np.array(compute_spatial_entropy({"a": v}, L, EntropyConfig(use_weight_distribution=False))[0])
+    out["single_weighted"] = np.array(compute_spatial_entropy({"a": v}, L, EntropyConfig())[0])
+    # no tile inside a tiny FoV -> 0.0
+    e, w, a = compute_spatial_entropy({"a": v, "b": v2}, L, EntropyConfig(fov_angle=1.0))
+    out["tiny_fov"] = np.array(e)
+    out["tiny_fov_nweights"] = np.array(len(w))
+    out["tiny_fov_assign"] = np.array([a["a"], a["b"]])
+    # one-tile lattice -> nan
+    out["one_tile"] = np.array(compute_spatial_entropy({"a": v, "b": v2}, generate_fibonacci_lattice(1), EntropyConfig())[0])
+    # transition single pair -> nan ; two users
+    out["trans_single"] = np.array(compute_transition_entropy({"a": v}, {"a": v2}, L, EntropyConfig(), 120)[0])
+    out["trans_two"] = np.array(compute_transition_entropy({"a": v, "b": v2}, {"a": v2, "b": v}, L, EntropyConfig(), 120)[0])
+    for name, fn in (("spatial_empty", lambda: compute_spatial_entropy({}, L, EntropyConfig())),
+                     ("trans_empty", lambda: compute_transition_entropy({}, {"a": v}, L, EntropyConfig(), 120)),
+                     ("trans_disjoint", lambda: compute_transition_entropy({"a": v}, {"b": v}, L, EntropyConfig(), 120))):
+        try:
+            fn()
+            out[name] = np.array("none")
+        except Exception as e:  # noqa: BLE001
+            out[name] = np.array(type(e).__name__)
+    np.savez_compressed(OUT / "g9_operator_edges.npz", **out)
+    print("G9", {k: out[k] for k in ("single_unweighted", "tiny_fov", "one_tile", "trans_single", "spatial_empty",
+                                     "trans_empty", "trans_disjoint")})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--jobs", type=int, default=8)
+    args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+    OUT.mkdir(parents=True, exist_ok=True)
+    cwd = os.getcwd()
+    scratch = tempfile.mkdtemp(prefix="vet_golden_")
+    os.chdir(scratch)  # AnalyzerConfig() mkdirs ./output
+    vt = _import_reference()
+    synth = _load_synth()
+
+    def want(x):
+        return not only or x in only
+
+    if want("G1"):
+        g1_lattices(vt)
+    if want("G2"):
+        g2_quantiser(vt)
+    if want("G6"):
+        g6_ingest(vt)
+    if want("G7"):
+        g7_weight_rows(vt)
+    if want("G9"):
+        g9_operator_edges(vt)
+    if want("G8"):
+        g8_dense_transition(vt, synth)
+    if want("G4"):
+        g4_spatial(vt, synth)
+    if want("G5"):
+        g5_transition(vt, synth)
+    if want("G3"):
+        g3_nearest(vt, args.jobs)
+    os.chdir(cwd)
+
+
+if __name__ == "__main__":
+    main()
