@@ -1,0 +1,157 @@
+/*
+ * vet.h — C-ABI of the MI355X-native viewport -> Fibonacci-tile -> entropy engine.
+ *
+ * The reference (IamArmanNikkhah/viewport-entropy-toolkit) is pure Python and has
+ * no FFI layer; its boundary for this path is the Python API.  This library sits
+ * underneath a drop-in of that API and is bound with ctypes.
+ * Each entry point names the reference code it replaces; paths are relative to
+ * /root/reference/src/viewport_entropy_toolkit/.
+ *
+ * Conventions
+ *   - plain C symbols, plain pointers and sizes; no C++ or torch types;
+ *   - every function returns 0 on success or a negative VET_ERR_* code;
+ *     vet_last_error() gives the thread-local message of the last failure;
+ *   - the caller owns every buffer; the library keeps no caller pointer after a
+ *     call returns (device inputs of an asynchronous call must stay alive until
+ *     the stream has been synchronised);
+ *   - sample arrays are FRAME-MAJOR: element (frame f, user u) is at [f*U + u],
+ *     so one frame's users are contiguous (this is the dense form of the
+ *     reference's ``vectors_df``: one row per frame, one column per user);
+ *     an absent sample (reference: ``None`` cell) is NaN in mu or mv, or id -1;
+ *   - "d_" parameters are device pointers, "h_" parameters are host pointers;
+ *   - ``stream`` is a hipStream_t passed as void* (NULL = the context's stream).
+ *     Device-pointer entry points only enqueue work; they do not synchronise.
+ *   - there is no CPU fallback: without a gfx950 device vet_create() fails.
+ */
+#ifndef VET_H_
+#define VET_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VET_VERSION 100 /* 0.1.0 */
+
+enum {
+    VET_OK = 0,
+    VET_ERR_INVALID = -1,   /* bad argument (maps to ValueError / ValidationError) */
+    VET_ERR_DEVICE = -2,    /* HIP failure / no device (maps to RuntimeError) */
+    VET_ERR_RANGE = -3,     /* a 2dmu/2dmv value outside [0,1]  (reference: ValidationError,
+                               utilities/data_utils.py:256-257) */
+    VET_ERR_EMPTY = -4,     /* a frame without any (common) user (reference: ValidationError
+                               entropy_utils.py:170 / ZeroDivisionError entropy_utils.py:299) */
+    VET_ERR_UNSUPPORTED = -5
+};
+
+typedef struct vet_ctx vet_ctx;   /* one device + stream + scratch; one per thread */
+typedef struct vet_plan vet_plan; /* device tables for one analyzer configuration */
+
+/* ---- library / device ---------------------------------------------------- */
+int vet_version(void);
+const char *vet_last_error(void);
+int vet_device_count(void);
+int vet_create(int device_id, vet_ctx **out);
+int vet_destroy(vet_ctx *ctx);
+int vet_synchronize(vet_ctx *ctx);
+/* Per-kernel timing with hipEvents on the launch stream (bench.py's roofline leg). */
+int vet_profile_enable(vet_ctx *ctx, int on);
+int vet_profile_reset(vet_ctx *ctx);
+/* kernel ids: 0 grid_dirs, 1 nearest_lut, 2 spatial_hist, 3 transition, 4 finalize */
+int vet_profile_get(vet_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
+const char *vet_kernel_name(int kernel_id);
+
+/* ---- device memory helpers (for hosts without torch) --------------------- */
+int vet_malloc(vet_ctx *ctx, size_t bytes, void **d_ptr);
+int vet_free(vet_ctx *ctx, void *d_ptr);
+int vet_memcpy_h2d(vet_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int vet_memcpy_d2h(vet_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+
+/* ---- plan: what SpatialEntropyAnalyzer.__init__ + AnalyzerConfig hold ----- */
+typedef struct vet_plan_desc {
+    /* Quantiser of process_viewport_data + format_trajectory_data + Vector.from_spherical
+     * (utilities/data_utils.py:243-286, 390-397; data_types.py:204-216) as per-axis tables
+     * built by the host with the reference's own float operations:
+     *   lon axis, px = 0..W : cos(theta), sin(theta), theta = radians(lon(px))
+     *   lat axis, py = 0..H : sin(phi),   cos(phi),   phi   = radians(90 - lat(py))
+     * The device forms x = round6(sin(phi)*cos(theta)), y = round6(sin(phi)*sin(theta)),
+     * z = round6(cos(phi)).  Leave all four NULL and set dir_table for an explicit table. */
+    int video_width, video_height;
+    const double *h_lon_cos, *h_lon_sin; /* [W+1] */
+    const double *h_lat_sin, *h_lat_cos; /* [H+1] */
+    /* Alternative to the axis tables: explicit direction table (rounded Vector xyz), used by
+     * the operator-level compute_spatial_entropy / compute_transition_entropy shims
+     * (utilities/entropy_utils.py:147-151, 213-219) where callers pass arbitrary Vectors. */
+    const double *h_dir_table; /* [n_dirs*3] or NULL */
+    int64_t n_dirs;
+    /* Lattices: generate_fibonacci_lattice(tile_count) per AnalyzerConfig.tile_counts entry
+     * (analyzers/spatial_entropy.py:63-66), as rounded Vector xyz. */
+    int n_lattices;                 /* K >= 1 */
+    const int *n_tiles;             /* [K]  n_k = 2*floor(tile_count/2)+1 */
+    const double *const *h_tiles;   /* K pointers to [n_k*3] */
+    const double *h_max_entropy;    /* [K]  -n*(1/n)*log2(1/n), entropy_utils.py:201-203 */
+    /* EntropyConfig (utilities/entropy_utils.py:20-38) */
+    double fov_angle;               /* degrees, (0,360] */
+    double max_angular_distance;    /* np.radians(fov_angle/2), entropy_utils.py:124 */
+    double power_factor;            /* > 0 */
+    int use_weight_distribution;
+} vet_plan_desc;
+
+int vet_plan_create(vet_ctx *ctx, const vet_plan_desc *desc, vet_plan **out);
+int vet_plan_destroy(vet_plan *plan);
+int64_t vet_plan_n_dirs(const vet_plan *plan);
+/* Parity hooks: read back the device-built tables (synchronous). */
+int vet_plan_read_dirs(vet_plan *plan, double *h_xyz /* [n_dirs*3] rounded Vector xyz */);
+int vet_plan_read_nearest(vet_plan *plan, int lattice, int32_t *h_nearest /* [n_dirs] */);
+
+/* ---- hot path: SpatialEntropyAnalyzer.compute_entropy ---------------------
+ * (analyzers/spatial_entropy.py:107-164 -> entropy_utils.py:147-211, 108-144, 89-106, 41-87)
+ *   d_entropy [T]      mean over the plan's lattices of the normalised spatial entropy
+ *   d_assign  [T*U]    nearest tile of lattice 0 per sample, -1 absent      (nullable)
+ *   d_weights [T*n_0]  per-frame tile weight sums of lattice 0              (nullable)
+ *   d_present [T]      users present per frame                              (nullable)
+ *   d_status  [2]      {#samples outside [0,1], #frames without a user}; the call ADDS to
+ *                      it, the caller zeroes it                             (nullable)   */
+int vet_spatial_entropy(vet_plan *plan, const double *d_mu, const double *d_mv,
+                        int n_users, int n_frames,
+                        double *d_entropy, int32_t *d_assign, double *d_weights,
+                        int32_t *d_present, int32_t *d_status, void *stream);
+/* Same, samples given as direction ids into the plan's direction table (-1 absent). */
+int vet_spatial_entropy_ids(vet_plan *plan, const int32_t *d_ids, int n_users, int n_frames,
+                            double *d_entropy, int32_t *d_assign, double *d_weights,
+                            int32_t *d_present, int32_t *d_status, void *stream);
+
+/* ---- hot path: TransitionEntropyAnalyzer.compute_entropy ------------------
+ * (analyzers/transition_entropy.py:107-175 -> entropy_utils.py:213-332)
+ * Output row r compares frame r (prior) with frame r+1 (current), r = 0..T-2.
+ *   d_entropy  [T-1]
+ *   d_pairs    [(T-1)*U*2]  (prior tile, current tile) of lattice 0, -1 if not in both (nullable)
+ *   d_srccount [(T-1)*n_0]  users per source tile of lattice 0                          (nullable)
+ *   d_common   [T-1]        users present in both frames                                (nullable)
+ *   d_status   [2]          {#samples outside [0,1], #rows without a common user}       (nullable) */
+int vet_transition_entropy(vet_plan *plan, const double *d_mu, const double *d_mv,
+                           int n_users, int n_frames,
+                           double *d_entropy, int32_t *d_pairs, int32_t *d_srccount,
+                           int32_t *d_common, int32_t *d_status, void *stream);
+int vet_transition_entropy_ids(vet_plan *plan, const int32_t *d_ids, int n_users, int n_frames,
+                               double *d_entropy, int32_t *d_pairs, int32_t *d_srccount,
+                               int32_t *d_common, int32_t *d_status, void *stream);
+
+/* ---- host-buffer convenience: H2D, run, D2H, synchronous ------------------
+ * Return VET_ERR_RANGE / VET_ERR_EMPTY when the status words are non-zero (outputs are still
+ * written).  h_mu/h_mv may be NULL when h_ids is given and vice versa. */
+int vet_spatial_entropy_host(vet_plan *plan, const double *h_mu, const double *h_mv,
+                             const int32_t *h_ids, int n_users, int n_frames,
+                             double *h_entropy, int32_t *h_assign, double *h_weights,
+                             int32_t *h_present);
+int vet_transition_entropy_host(vet_plan *plan, const double *h_mu, const double *h_mv,
+                                const int32_t *h_ids, int n_users, int n_frames,
+                                double *h_entropy, int32_t *h_pairs, int32_t *h_srccount,
+                                int32_t *h_common);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VET_H_ */

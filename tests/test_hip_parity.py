@@ -1,0 +1,303 @@
+"""GPU parity: the HIP path (through the C-ABI) against the oracle and the golden vectors.
+
+Bars (BASELINE.json north_star): tile indices / direction tables bit-exact; entropy within
+1e-6 relative (asserted much tighter here: RTOL below), nan == nan.
+"""
+import numpy as np
+import pytest
+
+from oracle import vet_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9          # contract is 1e-6; the fixed-point histogram + FP64 entropy sits near 1e-13
+ATOL_W = 1e-12       # absolute tolerance on tile weight sums (fixed point resolution 2^-52 per add)
+
+
+@pytest.fixture(scope="module")
+def native():
+    from viewport_entropy_toolkit import _native
+    return _native
+
+
+@pytest.fixture(scope="module")
+def engine(native):
+    return native.Engine.default()
+
+
+def make_plan(native, engine, tcs, W=100, H=200, fov=120.0, power=2.0, weighted=True, dir_table=None):
+    tiles = [vo.fibonacci_lattice(tc) for tc in tcs]
+    return native.Plan(engine, tiles, fov, power, weighted, W, H, dir_table=dir_table)
+
+
+def load(golden_dir, name):
+    return np.load(golden_dir / name, allow_pickle=False)
+
+
+# --------------------------------------------------------------------------- tables
+@pytest.mark.parametrize("W,H", [(100, 200), (6, 4), (3840, 1920)])
+def test_grid_directions_bit_exact(native, engine, golden_dir, W, H):
+    plan = make_plan(native, engine, [20], W, H)
+    dirs = plan.read_dirs().reshape(H + 1, W + 1, 3)
+    g = load(golden_dir, "g2_quantiser.npz")
+    if (W, H) == (100, 200):
+        assert np.array_equal(dirs, g["vec_100x200"])
+    if (W, H) == (3840, 1920):
+        assert np.array_equal(dirs[g["big_py"], g["big_px"]], g["big_vec"])
+    assert np.array_equal(dirs, vo.direction_grid(W, H))
+    plan.close()
+
+
+def test_nearest_lut_exhaustive_vs_reference(native, engine, golden_dir):
+    g = load(golden_dir, "g3_nearest.npz")
+    tcs = sorted(int(k[2:]) for k in g.files)
+    plan = make_plan(native, engine, tcs)
+    for k, tc in enumerate(tcs):
+        near = plan.read_nearest(k).reshape(201, 101)
+        assert np.array_equal(near, g[f"tc{tc}"]), f"tile_count {tc}"
+    plan.close()
+
+
+def test_nearest_lut_large_grid_vs_oracle(native, engine):
+    W, H = 3840, 1920
+    plan = make_plan(native, engine, [50, 500], W, H)
+    rng = np.random.default_rng(3)
+    py, px = rng.integers(0, H + 1, 20000), rng.integers(0, W + 1, 20000)
+    lon, lat = vo.axis_tables(W, H)
+    dirs = vo.vector_from_spherical(lon[px], lat[py])
+    for k, tc in enumerate((50, 500)):
+        near = plan.read_nearest(k).reshape(H + 1, W + 1)[py, px]
+        assert np.array_equal(near, vo.nearest_tile(dirs, vo.fibonacci_lattice(tc)))
+    plan.close()
+
+
+# --------------------------------------------------------------------------- goldens
+def _g4_dense(g, tag):
+    cols = [str(c) for c in g[f"{tag}__columns"]]
+    order = [int(c[4:]) for c in cols]
+    tracks = [(g["time_in"][u], g["mu_in"][u], g["mv_in"][u]) for u in order]
+    return vo.format_trajectories(tracks)
+
+
+@pytest.mark.parametrize("tag,tcs,kw", [
+    ("w_tc50", [50], {}),
+    ("w_tc50_100_200", [50, 100, 200], {}),
+    ("u_tc50", [50], dict(weighted=False)),
+    ("u_tc20_50", [20, 50], dict(weighted=False)),
+    ("w_tc50_p15", [50], dict(power=1.5)),
+    ("w_tc50_fov90", [50], dict(fov=90.0)),
+    ("w_tc100_fov200_p05", [100], dict(fov=200.0, power=0.5)),
+])
+def test_spatial_vs_reference_goldens(native, engine, golden_dir, tag, tcs, kw):
+    g = load(golden_dir, "g4_spatial.npz")
+    _, mu, mv = _g4_dense(g, tag)
+    plan = make_plan(native, engine, tcs, **kw)
+    res = plan.spatial(mu=mu, mv=mv, want_assign=True, want_weights=True)
+    assert np.array_equal(res["assign"], g[f"{tag}__assign"])
+    np.testing.assert_allclose(res["entropy"], g[f"{tag}__entropy"], rtol=RTOL, equal_nan=True)
+    fr = g[f"{tag}__weights_frames"]
+    np.testing.assert_allclose(res["weights"][fr], g[f"{tag}__weights"], rtol=1e-9, atol=ATOL_W)
+    assert np.array_equal(res["present"], np.full(len(mu), mu.shape[1]))
+    plan.close()
+
+
+@pytest.mark.parametrize("tag,tcs", [("tc200", [200]), ("tc20_50", [20, 50])])
+def test_transition_vs_reference_goldens(native, engine, golden_dir, tag, tcs):
+    g = load(golden_dir, "g5_transition.npz")
+    _, mu, mv = _g4_dense(g, tag)
+    plan = make_plan(native, engine, tcs)
+    res = plan.transition(mu=mu, mv=mv, want_pairs=True, want_srccount=True)
+    assert np.array_equal(res["pairs"], g[f"{tag}__pairs"])
+    assert np.array_equal(res["srccount"], g[f"{tag}__srccount"])
+    np.testing.assert_allclose(res["entropy"], g[f"{tag}__entropy"], rtol=RTOL, equal_nan=True)
+    plan.close()
+
+
+@pytest.mark.parametrize("tc", [20, 50])
+def test_dense_transition_bucket_quirk(native, engine, golden_dir, tc):
+    """Many users per source tile: the int-key / stale-variable behaviour decides the value."""
+    g = load(golden_dir, "g8_dense_transition.npz")
+    px, py, present = g["px"], g["py"], g["present"]
+    mu = np.where(present, (px + 0.5) / 100.0, np.nan)
+    mv = np.where(present, (py + 0.5) / 200.0, np.nan)
+    mu[px == 100] = 1.0
+    mv[py == 200] = 1.0
+    mu[~present] = np.nan
+    mv[~present] = np.nan
+    plan = make_plan(native, engine, [tc])
+    res = plan.transition(mu=mu, mv=mv, want_pairs=True, want_srccount=True)
+    assert np.array_equal(res["pairs"], g[f"tc{tc}__pairs"])
+    assert np.array_equal(res["srccount"], g[f"tc{tc}__srccount"])
+    np.testing.assert_allclose(res["entropy"], g[f"tc{tc}__entropy"], rtol=RTOL, equal_nan=True)
+    plan.close()
+    for tag, weighted in (("u", False), ("w", True)):
+        plan = make_plan(native, engine, [tc], weighted=weighted)
+        res = plan.spatial(mu=mu, mv=mv)
+        np.testing.assert_allclose(res["entropy"], g[f"tc{tc}__spatial_{tag}"], rtol=RTOL, equal_nan=True)
+        assert np.array_equal(res["present"], present.sum(1))
+        plan.close()
+
+
+def test_ingest_edge_cases(native, engine, golden_dir):
+    g = load(golden_dir, "g6_ingest.npz")
+    for tag, weighted in (("w", True), ("u", False)):
+        cols = [str(c) for c in g[f"{tag}__columns"]]
+        tracks = [tuple(g[f"in_{c}"][:, i] for i in range(3)) for c in cols]
+        _, mu, mv = vo.format_trajectories(tracks)
+        plan = make_plan(native, engine, [50, 20], weighted=weighted)
+        res = plan.spatial(mu=mu, mv=mv)
+        assert np.array_equal(res["assign"], g[f"{tag}__assign"])
+        np.testing.assert_allclose(res["entropy"], g[f"{tag}__entropy"], rtol=RTOL, equal_nan=True)
+        # transition on this data has rows without a common user -> VET_ERR_EMPTY
+        tr = plan.transition(mu=mu, mv=mv, check=False)
+        assert tr["code"] == native.VET_ERR_EMPTY
+        assert (tr["common"] == 0).any() and np.isnan(tr["entropy"][tr["common"] == 0]).all()
+        with pytest.raises(native.NativeError):
+            plan.transition(mu=mu, mv=mv)
+        plan.close()
+
+
+def test_weight_rows_vs_reference(native, engine, golden_dir):
+    """One user per frame: the frame histogram is that direction's weight row."""
+    g = load(golden_dir, "g7_weight_rows.npz")
+    px, py = g["px"], g["py"]
+    mu = ((px + 0.5) / 100.0)[:, None]
+    mv = ((py + 0.5) / 200.0)[:, None]
+    mu[px == 100] = 1.0
+    mv[py == 200] = 1.0
+    for tag, tc, kw in (("tc500", 500, {}), ("tc50_p15_fov90", 50, dict(power=1.5, fov=90.0)),
+                        ("tc100_fov360", 100, dict(fov=360.0, power=3.0))):
+        plan = make_plan(native, engine, [tc], **kw)
+        res = plan.spatial(mu=mu, mv=mv, want_weights=True)
+        ref = g[f"{tag}__rows"]
+        np.testing.assert_allclose(res["weights"], ref, rtol=1e-9, atol=1e-15)
+        assert np.array_equal(res["assign"][:, 0], g[f"{tag}__nearest"])
+        plan.close()
+
+
+# --------------------------------------------------------------------------- oracle, larger
+def test_out_of_range_and_absent(native, engine):
+    mu = np.array([[0.5, 1.5], [0.2, 0.3]])
+    mv = np.array([[0.5, 0.5], [0.2, np.nan]])
+    plan = make_plan(native, engine, [50])
+    res = plan.spatial(mu=mu, mv=mv, check=False)
+    assert res["code"] == native.VET_ERR_RANGE
+    with pytest.raises(native.NativeError) as ei:
+        plan.spatial(mu=mu, mv=mv)
+    assert ei.value.code == native.VET_ERR_RANGE
+    mu[0, 1] = np.nan
+    mu[1, 0] = np.nan
+    res = plan.spatial(mu=mu, mv=mv, check=False)
+    assert res["code"] == native.VET_ERR_EMPTY and res["present"].tolist() == [1, 0]
+    assert res["assign"].tolist()[1] == [-1, -1] and np.isnan(res["entropy"][1])
+    plan.close()
+
+
+@pytest.mark.parametrize("weighted", [True, False])
+def test_config2_vs_oracle(native, engine, weighted):
+    """BASELINE config 2: 64 users x 3000 frames, tile_counts=[50,100,200]."""
+    from viewport_entropy_toolkit import _synthetic
+    mu, mv = _synthetic.random_walk_video(64, 3000, base_seed=77, p_absent=0.05)
+    tcs = [50, 100, 200]
+    plan = make_plan(native, engine, tcs, weighted=weighted)
+    res = plan.spatial(mu=mu, mv=mv, want_weights=True)
+    ent, assign, weights = vo.spatial_series(mu, mv, 100, 200, tcs, use_weight_distribution=weighted,
+                                             want_weights=True)
+    assert np.array_equal(res["assign"], assign)
+    np.testing.assert_allclose(res["entropy"], ent, rtol=RTOL, equal_nan=True)
+    np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=ATOL_W)
+    plan.close()
+
+
+def test_transition_random_vs_oracle(native, engine):
+    from viewport_entropy_toolkit import _synthetic
+    mu, mv = _synthetic.random_walk_video(96, 400, base_seed=5, p_absent=0.1)
+    for tcs in ([200], [20, 50]):
+        plan = make_plan(native, engine, tcs)
+        res = plan.transition(mu=mu, mv=mv)
+        ent, pairs = vo.transition_series(mu, mv, 100, 200, tcs)
+        assert np.array_equal(res["pairs"], pairs)
+        np.testing.assert_allclose(res["entropy"], ent, rtol=RTOL, equal_nan=True)
+        plan.close()
+
+
+def test_explicit_direction_table_ids(native, engine):
+    """The *_ids entry points (operator boundary): arbitrary Vectors, not on the pixel grid."""
+    rng = np.random.default_rng(9)
+    lon, lat = rng.uniform(-180, 180, 300), rng.uniform(-90, 90, 300)
+    table = vo.vector_from_spherical(np.round(lon, 1), np.round(lat, 1))
+    ids = rng.integers(0, 300, (50, 24)).astype(np.int32)
+    ids[rng.random(ids.shape) < 0.1] = -1
+    ids[:, 0] = np.abs(ids[:, 0])
+    L = vo.fibonacci_lattice(100)
+    plan = make_plan(native, engine, [100], dir_table=table)
+    res = plan.spatial(ids=ids, want_weights=True)
+    for t in range(len(ids)):
+        d = table[ids[t][ids[t] >= 0]]
+        e, hist, near = vo.spatial_entropy_frame(d, L)
+        np.testing.assert_allclose(res["entropy"][t], e, rtol=RTOL)
+        np.testing.assert_allclose(res["weights"][t], hist, rtol=1e-9, atol=ATOL_W)
+        assert np.array_equal(res["assign"][t][ids[t] >= 0], near)
+    tr = plan.transition(ids=ids)
+    near_all = vo.nearest_tile(table, L)
+    for t in range(1, len(ids)):
+        both = (ids[t] >= 0) & (ids[t - 1] >= 0)
+        e = vo.transition_entropy_closed_form(near_all[ids[t - 1][both]], near_all[ids[t][both]], len(L))
+        np.testing.assert_allclose(tr["entropy"][t - 1], e, rtol=RTOL, equal_nan=True)
+    plan.close()
+
+
+# --------------------------------------------------------------------------- full size, properties
+def test_config3_full_size_properties(native, engine):
+    """BASELINE config 3 (1024 users x 30000 frames, tile_counts=[500]): too big for the oracle
+    as a whole, so: bit-reproducibility, invariance under user permutation and under splitting
+    the frame axis (both exact thanks to the integer histogram), nearest == LUT, and a sample of
+    frames against the oracle."""
+    from viewport_entropy_toolkit import _synthetic
+    U, T = 1024, 30000
+    rng = np.random.default_rng(2)
+    # cheap to generate: a random walk over frames for all users at once
+    mu = np.mod(0.5 + np.cumsum(rng.normal(0, 0.01, (T, U)), axis=0), 1.0)
+    mv = np.clip(0.5 + np.cumsum(rng.normal(0, 0.005, (T, U)), axis=0), 0.0, 1.0)
+    plan = make_plan(native, engine, [500])
+    a = plan.spatial(mu=mu, mv=mv, want_assign=True)
+    b = plan.spatial(mu=mu, mv=mv, want_assign=False)
+    assert np.array_equal(a["entropy"], b["entropy"])                    # run-to-run bit exact
+    assert np.all(np.isfinite(a["entropy"])) and a["entropy"].min() > 0 and a["entropy"].max() <= 1.0
+    perm = rng.permutation(U)
+    c = plan.spatial(mu=mu[:8000, perm], mv=mv[:8000, perm], want_assign=False)
+    assert np.array_equal(c["entropy"], a["entropy"][:8000])             # order independent
+    d = plan.spatial(mu=mu[12345:20001], mv=mv[12345:20001], want_assign=False)
+    assert np.array_equal(d["entropy"], a["entropy"][12345:20001])       # frame-axis split
+    near = plan.read_nearest(0).reshape(201, 101)
+    px, py = (mu * 100).astype(int), (mv * 200).astype(int)
+    assert np.array_equal(a["assign"], near[py, px])
+    frames = rng.integers(0, T, 12)
+    ent, assign, _ = vo.spatial_series(mu[frames], mv[frames], 100, 200, [500])
+    assert np.array_equal(a["assign"][frames], assign)
+    np.testing.assert_allclose(a["entropy"][frames], ent, rtol=RTOL)
+    plan.close()
+
+
+def test_config5_transition_full_size_properties(native, engine):
+    """BASELINE config 5: 512 users x 10000 frames, tile_counts=[200], transition mode."""
+    U, T = 512, 10000
+    rng = np.random.default_rng(4)
+    mu = np.mod(0.5 + np.cumsum(rng.normal(0, 0.01, (T, U)), axis=0), 1.0)
+    mv = np.clip(0.5 + np.cumsum(rng.normal(0, 0.005, (T, U)), axis=0), 0.0, 1.0)
+    plan = make_plan(native, engine, [200])
+    a = plan.transition(mu=mu, mv=mv, want_pairs=True, want_srccount=True)
+    b = plan.transition(mu=mu, mv=mv, want_pairs=False)
+    assert np.array_equal(a["entropy"], b["entropy"])
+    assert (a["common"] == U).all() and (a["srccount"].sum(1) == U).all()
+    # halo split: rows [r0, r1) need frames [r0, r1]
+    d = plan.transition(mu=mu[4000:7001], mv=mv[4000:7001], want_pairs=False)
+    assert np.array_equal(d["entropy"], a["entropy"][4000:7000])
+    near = plan.read_nearest(0).reshape(201, 101)
+    tile = near[(mv * 200).astype(int), (mu * 100).astype(int)]
+    assert np.array_equal(a["pairs"][..., 0], tile[:-1]) and np.array_equal(a["pairs"][..., 1], tile[1:])
+    rows = rng.integers(0, T - 1, 40)
+    for r in rows:
+        e = vo.transition_entropy_pairs(tile[r], tile[r + 1], 201)
+        np.testing.assert_allclose(a["entropy"][r], e, rtol=RTOL)
+    plan.close()

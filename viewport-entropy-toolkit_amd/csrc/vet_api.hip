@@ -1,0 +1,641 @@
+// vet_api.hip — C-ABI (include/vet.h) over the gfx950 kernels in vet_kernels.hpp.
+//
+// Host responsibilities: device tables of a plan (direction table, unit lattices, one
+// nearest-tile LUT per lattice), launch geometry, a grow-only workspace (no hipMalloc in the
+// steady state), optional hipEvent timing per kernel.  There is no CPU compute path here.
+#include "../../include/vet.h"
+#include "vet_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(VET_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+enum { KID_GRID = 0, KID_NEAREST = 1, KID_SPATIAL = 2, KID_TRANSITION = 3, KID_FINALIZE = 4, KID_COUNT = 5 };
+const char* const kKernelNames[KID_COUNT] = {"k_grid_dirs", "k_nearest_lut", "k_spatial", "k_transition",
+                                             "k_finalize"};
+
+struct EventPair {
+    int kid;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct vet_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_cu = 256;
+    size_t lds_max = 64 * 1024;
+    // grow-only workspace for per-lattice entropies + status words of the host variants
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<EventPair> pending;
+    std::vector<hipEvent_t> free_events;
+    double prof_ms[KID_COUNT] = {0, 0, 0, 0, 0};
+    int64_t prof_n[KID_COUNT] = {0, 0, 0, 0, 0};
+};
+
+struct Lattice {
+    int n = 0;
+    double* d_tiles = nullptr;     // [n][3] unit
+    uint16_t* d_nearest = nullptr; // [n_dirs]
+    double hmax = 0.0;
+};
+
+struct vet_plan {
+    vet_ctx* ctx = nullptr;
+    int W = 0, H = 0;
+    bool grid = false;
+    int64_t n_dirs = 0;
+    double* d_dir_raw = nullptr;
+    double* d_dir_unit = nullptr;
+    std::vector<Lattice> lat;
+    double fov = 120.0, max_ang = 0.0, power = 2.0;
+    int weighted = 1;
+    double cos_cull = 0.0;
+};
+
+namespace {
+
+struct ProfScope {
+    vet_ctx* c;
+    hipStream_t s;
+    int kid;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(vet_ctx* c_, hipStream_t s_, int kid_) : c(c_), s(s_), kid(kid_) {
+        if (!c->profiling) return;
+        auto get = [&]() {
+            hipEvent_t e = nullptr;
+            if (!c->free_events.empty()) { e = c->free_events.back(); c->free_events.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        a = get(); b = get();
+        (void)hipEventRecord(a, s);
+    }
+    ~ProfScope() {
+        if (!a) return;
+        (void)hipEventRecord(b, s);
+        c->pending.push_back({kid, a, b});
+    }
+};
+
+int collect_profile(vet_ctx* c) {
+    for (auto& ep : c->pending) {
+        HIP_TRY(hipEventSynchronize(ep.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ep.a, ep.b));
+        c->prof_ms[ep.kid] += ms;
+        c->prof_n[ep.kid] += 1;
+        c->free_events.push_back(ep.a);
+        c->free_events.push_back(ep.b);
+    }
+    c->pending.clear();
+    return VET_OK;
+}
+
+int ensure_ws(vet_ctx* c, size_t bytes) {
+    if (bytes <= c->ws_bytes) return VET_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->ws) HIP_TRY(hipFree(c->ws));
+    c->ws = nullptr;
+    c->ws_bytes = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipMalloc(&c->ws, want));
+    c->ws_bytes = want;
+    return VET_OK;
+}
+
+int grid_for(long work, int block, int n_cu) {
+    long b = (work + block - 1) / block;
+    long cap = (long)n_cu * 8;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// fixed-point scale: sums of up to U weights in [0,1] must stay below 2^62
+double fx_scale_for(int U) {
+    int bits = 0;
+    while ((1L << bits) < (long)(U < 2 ? 2 : U)) ++bits;
+    return std::ldexp(1.0, 62 - bits);
+}
+
+struct Geometry {
+    int NW, FPW, G, UC;
+    size_t lds;
+};
+
+// launch geometry of k_spatial for a lattice of n tiles and U users
+int spatial_geometry(const vet_ctx* c, int n, int U, bool weighted, Geometry* g) {
+    g->G = (n + vet::WAVE - 1) / vet::WAVE;
+    if (g->G >= 4) { g->NW = g->G > 16 ? 16 : g->G; g->FPW = 1; }
+    else { g->NW = 4; g->FPW = 4 / g->G; }
+    if (!weighted) { g->NW = 4; g->FPW = U >= 256 ? 1 : (U >= 64 ? 4 : 16); }
+    g->UC = U < 1024 ? U : 1024;
+    auto lds_of = [&](int fpw, int uc) {
+        size_t b = (size_t)fpw * n * 8;
+        b += (size_t)fpw * uc * 24;
+        b += (size_t)g->NW * vet::QCAP * (8 + 2);
+        b += (size_t)2 * fpw * 4 + 64;
+        return b;
+    };
+    while (lds_of(g->FPW, g->UC) > c->lds_max && g->FPW > 1) g->FPW /= 2;
+    while (lds_of(g->FPW, g->UC) > c->lds_max && g->UC > 64) g->UC /= 2;
+    g->lds = lds_of(g->FPW, g->UC);
+    if (g->lds > c->lds_max)
+        return fail(VET_ERR_UNSUPPORTED, "lattice of %d tiles does not fit the LDS histogram (%zu B)", n, g->lds);
+    return VET_OK;
+}
+
+template <bool FROM_IDS>
+int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double* d_entropy, int32_t* d_assign,
+                   double* d_weights, int32_t* d_present, int32_t* d_status, hipStream_t s) {
+    vet_ctx* c = pl->ctx;
+    const int K = (int)pl->lat.size();
+    double* ent_k = d_entropy;
+    if (K > 1) {
+        int rc = ensure_ws(c, (size_t)K * T * sizeof(double));
+        if (rc) return rc;
+        ent_k = (double*)c->ws;
+    }
+    for (int k = 0; k < K; ++k) {
+        const Lattice& L = pl->lat[k];
+        Geometry g;
+        int rc = spatial_geometry(c, L.n, U, pl->weighted != 0, &g);
+        if (rc) return rc;
+        vet::SpatialParams p;
+        p.src = src;
+        p.U = U; p.T = T;
+        p.dir_unit = pl->d_dir_unit;
+        p.nearest = L.d_nearest;
+        p.tiles = L.d_tiles;
+        p.n = L.n;
+        p.weighted = pl->weighted;
+        p.cos_cull = pl->cos_cull;
+        p.wc.max_ang = pl->max_ang;
+        p.wc.power = pl->power;
+        p.wc.power_mode = pl->power == 2.0 ? 2 : (pl->power == 1.0 ? 1 : 0);
+        p.wc.fx_scale = fx_scale_for(U);
+        p.hmax = L.hmax;
+        p.ent_k = ent_k + (size_t)k * T;
+        p.assign = k == 0 ? d_assign : nullptr;
+        p.weights = k == 0 ? d_weights : nullptr;
+        p.present = k == 0 ? d_present : nullptr;
+        p.status = k == 0 ? d_status : nullptr;
+        p.FPW = g.FPW; p.G = g.G; p.UC = g.UC;
+        const int blocks = (T + g.FPW - 1) / g.FPW;
+        ProfScope ps(c, s, KID_SPATIAL);
+        hipLaunchKernelGGL((vet::k_spatial<FROM_IDS, true>), dim3(blocks), dim3(g.NW * vet::WAVE), g.lds, s, p);
+        HIP_TRY(hipGetLastError());
+    }
+    if (K > 1) {
+        ProfScope ps(c, s, KID_FINALIZE);
+        hipLaunchKernelGGL(vet::k_finalize, dim3(grid_for(T, 256, c->n_cu)), dim3(256), 0, s, ent_k, K, (long)T,
+                           d_entropy);
+        HIP_TRY(hipGetLastError());
+    }
+    return VET_OK;
+}
+
+template <bool FROM_IDS>
+int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double* d_entropy, int32_t* d_pairs,
+                      int32_t* d_srccount, int32_t* d_common, int32_t* d_status, hipStream_t s) {
+    vet_ctx* c = pl->ctx;
+    const int K = (int)pl->lat.size();
+    const int R = T - 1;
+    if (R <= 0) return VET_OK;
+    double* ent_k = d_entropy;
+    if (K > 1) {
+        int rc = ensure_ws(c, (size_t)K * R * sizeof(double));
+        if (rc) return rc;
+        ent_k = (double*)c->ws;
+    }
+    int HS = 64, lg = 6;
+    while (HS < 2 * U) { HS <<= 1; ++lg; }
+    for (int k = 0; k < K; ++k) {
+        const Lattice& L = pl->lat[k];
+        size_t lds = 16 * 8 + 8 + (size_t)5 * L.n * 4 + (size_t)3 * HS * 4 + (size_t)U * 4 + 16;
+        if (lds > c->lds_max)
+            return fail(VET_ERR_UNSUPPORTED, "transition kernel: %d users x %d tiles need %zu B of LDS (max %zu)", U,
+                        L.n, lds, c->lds_max);
+        vet::TransParams p;
+        p.src = src;
+        p.U = U; p.T = T;
+        p.nearest = L.d_nearest;
+        p.n = L.n;
+        p.hmax = L.hmax;
+        p.ent_k = ent_k + (size_t)k * R;
+        p.pairs = k == 0 ? d_pairs : nullptr;
+        p.srccount = k == 0 ? d_srccount : nullptr;
+        p.common = k == 0 ? d_common : nullptr;
+        p.status = k == 0 ? d_status : nullptr;
+        p.HS = HS; p.hs_shift = 32 - lg;
+        const int threads = U >= 512 ? 512 : 256;
+        ProfScope ps(c, s, KID_TRANSITION);
+        hipLaunchKernelGGL((vet::k_transition<FROM_IDS>), dim3(R), dim3(threads), lds, s, p);
+        HIP_TRY(hipGetLastError());
+    }
+    if (K > 1) {
+        ProfScope ps(c, s, KID_FINALIZE);
+        hipLaunchKernelGGL(vet::k_finalize, dim3(grid_for(R, 256, c->n_cu)), dim3(256), 0, s, ent_k, K, (long)R,
+                           d_entropy);
+        HIP_TRY(hipGetLastError());
+    }
+    return VET_OK;
+}
+
+int check_run_args(const vet_plan* pl, int U, int T, const void* out) {
+    if (!pl) return fail(VET_ERR_INVALID, "plan is NULL");
+    if (U <= 0 || T <= 0) return fail(VET_ERR_INVALID, "n_users and n_frames must be positive (got %d, %d)", U, T);
+    if (!out) return fail(VET_ERR_INVALID, "entropy output pointer is NULL");
+    return VET_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int vet_version(void) { return VET_VERSION; }
+const char* vet_last_error(void) { return g_err.c_str(); }
+const char* vet_kernel_name(int kid) { return (kid >= 0 && kid < KID_COUNT) ? kKernelNames[kid] : ""; }
+
+int vet_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int vet_create(int device_id, vet_ctx** out) {
+    if (!out) return fail(VET_ERR_INVALID, "out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(VET_ERR_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(VET_ERR_INVALID, "device_id %d out of range [0,%d)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    vet_ctx* c = new vet_ctx();
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // keep two workgroups per CU resident: cap a workgroup at half of the 160 KiB LDS
+    c->lds_max = prop.sharedMemPerBlock >= 160 * 1024 ? 80 * 1024 : (size_t)prop.sharedMemPerBlock;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c;
+    return VET_OK;
+}
+
+int vet_destroy(vet_ctx* c) {
+    if (!c) return VET_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& ep : c->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    for (auto e : c->free_events) (void)hipEventDestroy(e);
+    if (c->ws) (void)hipFree(c->ws);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return VET_OK;
+}
+
+int vet_synchronize(vet_ctx* c) {
+    if (!c) return fail(VET_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VET_OK;
+}
+
+int vet_profile_enable(vet_ctx* c, int on) {
+    if (!c) return fail(VET_ERR_INVALID, "ctx is NULL");
+    c->profiling = on != 0;
+    return VET_OK;
+}
+int vet_profile_reset(vet_ctx* c) {
+    if (!c) return fail(VET_ERR_INVALID, "ctx is NULL");
+    int rc = collect_profile(c);
+    if (rc) return rc;
+    for (int i = 0; i < KID_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+    return VET_OK;
+}
+int vet_profile_get(vet_ctx* c, int kid, double* total_ms, int64_t* launches) {
+    if (!c || kid < 0 || kid >= KID_COUNT) return fail(VET_ERR_INVALID, "bad ctx or kernel id");
+    int rc = collect_profile(c);
+    if (rc) return rc;
+    if (total_ms) *total_ms = c->prof_ms[kid];
+    if (launches) *launches = c->prof_n[kid];
+    return VET_OK;
+}
+
+int vet_malloc(vet_ctx* c, size_t bytes, void** d_ptr) {
+    if (!c || !d_ptr) return fail(VET_ERR_INVALID, "ctx or d_ptr is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 8));
+    return VET_OK;
+}
+int vet_free(vet_ctx* c, void* d_ptr) {
+    if (!c) return fail(VET_ERR_INVALID, "ctx is NULL");
+    if (d_ptr) HIP_TRY(hipFree(d_ptr));
+    return VET_OK;
+}
+int vet_memcpy_h2d(vet_ctx* c, void* d, const void* h, size_t bytes) {
+    if (!c) return fail(VET_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VET_OK;
+}
+int vet_memcpy_d2h(vet_ctx* c, void* h, const void* d, size_t bytes) {
+    if (!c) return fail(VET_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VET_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
+    if (!c || !d || !out) return fail(VET_ERR_INVALID, "ctx, desc or out is NULL");
+    const bool grid = d->h_lon_cos && d->h_lon_sin && d->h_lat_sin && d->h_lat_cos;
+    if (!grid && !(d->h_dir_table && d->n_dirs > 0))
+        return fail(VET_ERR_INVALID, "plan needs the four axis tables or an explicit direction table");
+    if (grid && (d->video_width <= 0 || d->video_height <= 0))
+        return fail(VET_ERR_INVALID, "Video dimensions must be positive");
+    if (d->n_lattices <= 0 || !d->n_tiles || !d->h_tiles || !d->h_max_entropy)
+        return fail(VET_ERR_INVALID, "Must specify at least one tile count");
+    if (!(d->fov_angle > 0.0 && d->fov_angle <= 360.0))
+        return fail(VET_ERR_INVALID, "FOV angle must be between 0 and 360 degrees");
+    if (!(d->power_factor > 0.0)) return fail(VET_ERR_INVALID, "Power factor must be positive");
+    for (int k = 0; k < d->n_lattices; ++k) {
+        if (d->n_tiles[k] <= 0 || d->n_tiles[k] > 65535 || !d->h_tiles[k])
+            return fail(VET_ERR_INVALID, "lattice %d: tile count %d outside [1, 65535]", k, d->n_tiles[k]);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    vet_plan* pl = new vet_plan();
+    pl->ctx = c;
+    pl->grid = grid;
+    pl->W = d->video_width; pl->H = d->video_height;
+    pl->fov = d->fov_angle; pl->max_ang = d->max_angular_distance; pl->power = d->power_factor;
+    pl->weighted = d->use_weight_distribution ? 1 : 0;
+    // conservative cull on the cosine; the exact 'distance < max' test runs on the survivors
+    pl->cos_cull = pl->max_ang >= 3.14159 ? -2.0 : std::cos(pl->max_ang) - 1e-9;
+    pl->n_dirs = grid ? (int64_t)(pl->W + 1) * (pl->H + 1) : d->n_dirs;
+    if (pl->n_dirs >= (1LL << 31)) { delete pl; return fail(VET_ERR_UNSUPPORTED, "direction table too large"); }
+
+    auto cleanup = [&](int rc) { vet_plan_destroy(pl); return rc; };
+#define PLAN_TRY(expr)                                                                           \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return cleanup(fail(VET_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_))); \
+    } while (0)
+
+    PLAN_TRY(hipMalloc((void**)&pl->d_dir_raw, (size_t)pl->n_dirs * 3 * sizeof(double)));
+    PLAN_TRY(hipMalloc((void**)&pl->d_dir_unit, (size_t)pl->n_dirs * 3 * sizeof(double)));
+    if (grid) {
+        const size_t nw = (size_t)pl->W + 1, nh = (size_t)pl->H + 1;
+        double* d_axes = nullptr;
+        PLAN_TRY(hipMalloc((void**)&d_axes, (2 * nw + 2 * nh) * sizeof(double)));
+        hipError_t e1 = hipMemcpyAsync(d_axes, d->h_lon_cos, nw * 8, hipMemcpyHostToDevice, s);
+        hipError_t e2 = hipMemcpyAsync(d_axes + nw, d->h_lon_sin, nw * 8, hipMemcpyHostToDevice, s);
+        hipError_t e3 = hipMemcpyAsync(d_axes + 2 * nw, d->h_lat_sin, nh * 8, hipMemcpyHostToDevice, s);
+        hipError_t e4 = hipMemcpyAsync(d_axes + 2 * nw + nh, d->h_lat_cos, nh * 8, hipMemcpyHostToDevice, s);
+        if (e1 || e2 || e3 || e4) { (void)hipFree(d_axes); return cleanup(fail(VET_ERR_DEVICE, "axis table upload failed")); }
+        {
+            ProfScope ps(c, s, KID_GRID);
+            hipLaunchKernelGGL(vet::k_grid_dirs, dim3(grid_for(pl->n_dirs, 256, c->n_cu)), dim3(256), 0, s, d_axes,
+                               d_axes + nw, d_axes + 2 * nw, d_axes + 2 * nw + nh, pl->W, pl->H, pl->d_dir_raw,
+                               pl->d_dir_unit);
+        }
+        hipError_t e5 = hipStreamSynchronize(s);
+        (void)hipFree(d_axes);
+        if (e5 != hipSuccess) return cleanup(fail(VET_ERR_DEVICE, "k_grid_dirs failed: %s", hipGetErrorString(e5)));
+    } else {
+        PLAN_TRY(hipMemcpyAsync(pl->d_dir_raw, d->h_dir_table, (size_t)pl->n_dirs * 24, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(vet::k_unit_dirs, dim3(grid_for(pl->n_dirs, 256, c->n_cu)), dim3(256), 0, s, pl->d_dir_raw,
+                           (long)pl->n_dirs, pl->d_dir_unit);
+        PLAN_TRY(hipStreamSynchronize(s));
+    }
+    pl->lat.resize(d->n_lattices);
+    for (int k = 0; k < d->n_lattices; ++k) {
+        Lattice& L = pl->lat[k];
+        L.n = d->n_tiles[k];
+        L.hmax = d->h_max_entropy[k];
+        std::vector<double> unit((size_t)L.n * 3);
+        for (int t = 0; t < L.n; ++t) {
+            const double x = d->h_tiles[k][3 * t], y = d->h_tiles[k][3 * t + 1], z = d->h_tiles[k][3 * t + 2];
+            const double len = std::sqrt(x * x + y * y + z * z);
+            if (!(len > 0.0)) return cleanup(fail(VET_ERR_INVALID, "Vector cannot have zero length (lattice %d tile %d)", k, t));
+            unit[3 * t] = x / len; unit[3 * t + 1] = y / len; unit[3 * t + 2] = z / len;
+        }
+        PLAN_TRY(hipMalloc((void**)&L.d_tiles, unit.size() * sizeof(double)));
+        PLAN_TRY(hipMalloc((void**)&L.d_nearest, (size_t)pl->n_dirs * sizeof(uint16_t)));
+        PLAN_TRY(hipMemcpyAsync(L.d_tiles, unit.data(), unit.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        PLAN_TRY(hipStreamSynchronize(s));   // 'unit' goes out of scope
+        const size_t lds = (size_t)L.n * 3 * sizeof(double);
+        if (lds > 160 * 1024 - 1024) return cleanup(fail(VET_ERR_UNSUPPORTED, "lattice of %d tiles exceeds the LDS tile cache", L.n));
+        if (lds > 64 * 1024)
+            PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_nearest_lut, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        {
+            ProfScope ps(c, s, KID_NEAREST);
+            hipLaunchKernelGGL(vet::k_nearest_lut, dim3(grid_for(pl->n_dirs, 64, c->n_cu * 4)), dim3(64), lds, s,
+                               pl->d_dir_unit, (long)pl->n_dirs, L.d_tiles, L.n, L.d_nearest);
+        }
+        PLAN_TRY(hipGetLastError());
+    }
+    PLAN_TRY(hipStreamSynchronize(s));
+    // the run kernels may need more than the default 64 KiB of dynamic LDS
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_transition<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+#undef PLAN_TRY
+    *out = pl;
+    return VET_OK;
+}
+
+int vet_plan_destroy(vet_plan* pl) {
+    if (!pl) return VET_OK;
+    (void)hipSetDevice(pl->ctx->device);
+    (void)hipStreamSynchronize(pl->ctx->stream);
+    if (pl->d_dir_raw) (void)hipFree(pl->d_dir_raw);
+    if (pl->d_dir_unit) (void)hipFree(pl->d_dir_unit);
+    for (auto& L : pl->lat) {
+        if (L.d_tiles) (void)hipFree(L.d_tiles);
+        if (L.d_nearest) (void)hipFree(L.d_nearest);
+    }
+    delete pl;
+    return VET_OK;
+}
+
+int64_t vet_plan_n_dirs(const vet_plan* pl) { return pl ? pl->n_dirs : 0; }
+
+int vet_plan_read_dirs(vet_plan* pl, double* h_xyz) {
+    if (!pl || !h_xyz) return fail(VET_ERR_INVALID, "plan or output is NULL");
+    HIP_TRY(hipMemcpy(h_xyz, pl->d_dir_raw, (size_t)pl->n_dirs * 24, hipMemcpyDeviceToHost));
+    return VET_OK;
+}
+
+int vet_plan_read_nearest(vet_plan* pl, int k, int32_t* h_nearest) {
+    if (!pl || !h_nearest) return fail(VET_ERR_INVALID, "plan or output is NULL");
+    if (k < 0 || k >= (int)pl->lat.size()) return fail(VET_ERR_INVALID, "lattice index %d out of range", k);
+    std::vector<uint16_t> tmp((size_t)pl->n_dirs);
+    HIP_TRY(hipMemcpy(tmp.data(), pl->lat[k].d_nearest, tmp.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tmp.size(); ++i) h_nearest[i] = tmp[i];
+    return VET_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int vet_spatial_entropy(vet_plan* pl, const double* d_mu, const double* d_mv, int U, int T, double* d_entropy,
+                        int32_t* d_assign, double* d_weights, int32_t* d_present, int32_t* d_status, void* stream) {
+    int rc = check_run_args(pl, U, T, d_entropy);
+    if (rc) return rc;
+    if (!pl->grid) return fail(VET_ERR_INVALID, "plan has no pixel grid; use vet_spatial_entropy_ids");
+    if (!d_mu || !d_mv) return fail(VET_ERR_INVALID, "d_mu / d_mv is NULL");
+    vet::SampleSrc src{d_mu, d_mv, nullptr, pl->W, pl->H, (long)pl->n_dirs};
+    return launch_spatial<false>(pl, src, U, T, d_entropy, d_assign, d_weights, d_present, d_status,
+                                 stream ? (hipStream_t)stream : pl->ctx->stream);
+}
+
+int vet_spatial_entropy_ids(vet_plan* pl, const int32_t* d_ids, int U, int T, double* d_entropy, int32_t* d_assign,
+                            double* d_weights, int32_t* d_present, int32_t* d_status, void* stream) {
+    int rc = check_run_args(pl, U, T, d_entropy);
+    if (rc) return rc;
+    if (!d_ids) return fail(VET_ERR_INVALID, "d_ids is NULL");
+    vet::SampleSrc src{nullptr, nullptr, d_ids, pl->W, pl->H, (long)pl->n_dirs};
+    return launch_spatial<true>(pl, src, U, T, d_entropy, d_assign, d_weights, d_present, d_status,
+                                stream ? (hipStream_t)stream : pl->ctx->stream);
+}
+
+int vet_transition_entropy(vet_plan* pl, const double* d_mu, const double* d_mv, int U, int T, double* d_entropy,
+                           int32_t* d_pairs, int32_t* d_srccount, int32_t* d_common, int32_t* d_status,
+                           void* stream) {
+    int rc = check_run_args(pl, U, T, d_entropy);
+    if (rc) return rc;
+    if (!pl->grid) return fail(VET_ERR_INVALID, "plan has no pixel grid; use vet_transition_entropy_ids");
+    if (!d_mu || !d_mv) return fail(VET_ERR_INVALID, "d_mu / d_mv is NULL");
+    vet::SampleSrc src{d_mu, d_mv, nullptr, pl->W, pl->H, (long)pl->n_dirs};
+    return launch_transition<false>(pl, src, U, T, d_entropy, d_pairs, d_srccount, d_common, d_status,
+                                    stream ? (hipStream_t)stream : pl->ctx->stream);
+}
+
+int vet_transition_entropy_ids(vet_plan* pl, const int32_t* d_ids, int U, int T, double* d_entropy,
+                               int32_t* d_pairs, int32_t* d_srccount, int32_t* d_common, int32_t* d_status,
+                               void* stream) {
+    int rc = check_run_args(pl, U, T, d_entropy);
+    if (rc) return rc;
+    if (!d_ids) return fail(VET_ERR_INVALID, "d_ids is NULL");
+    vet::SampleSrc src{nullptr, nullptr, d_ids, pl->W, pl->H, (long)pl->n_dirs};
+    return launch_transition<true>(pl, src, U, T, d_entropy, d_pairs, d_srccount, d_common, d_status,
+                                   stream ? (hipStream_t)stream : pl->ctx->stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-buffer variants: stage through freshly allocated device buffers (not the hot path)
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t b) { return hipMalloc(&p, b ? b : 8); }
+};
+}  // namespace
+
+static int run_host(vet_plan* pl, bool transition, const double* h_mu, const double* h_mv, const int32_t* h_ids,
+                    int U, int T, double* h_entropy, int32_t* h_a, void* h_b, int32_t* h_c) {
+    int rc = check_run_args(pl, U, T, h_entropy);
+    if (rc) return rc;
+    const bool ids = h_ids != nullptr;
+    if (!ids && (!h_mu || !h_mv)) return fail(VET_ERR_INVALID, "need h_mu and h_mv, or h_ids");
+    if (!ids && !pl->grid) return fail(VET_ERR_INVALID, "plan has no pixel grid; pass h_ids");
+    vet_ctx* c = pl->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t S = (size_t)U * T;
+    const int R = transition ? T - 1 : T;
+    const int n0 = pl->lat[0].n;
+    DevBuf mu, mv, id, ent, a, b, cc, st;
+    if (ids) {
+        HIP_TRY(id.alloc(S * 4));
+        HIP_TRY(hipMemcpyAsync(id.p, h_ids, S * 4, hipMemcpyHostToDevice, s));
+    } else {
+        HIP_TRY(mu.alloc(S * 8));
+        HIP_TRY(mv.alloc(S * 8));
+        HIP_TRY(hipMemcpyAsync(mu.p, h_mu, S * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(mv.p, h_mv, S * 8, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(ent.alloc((size_t)(R > 0 ? R : 1) * 8));
+    const size_t a_bytes = transition ? (size_t)(R > 0 ? R : 0) * U * 2 * 4 : S * 4;
+    const size_t b_bytes = transition ? (size_t)(R > 0 ? R : 0) * n0 * 4 : (size_t)T * n0 * 8;
+    if (h_a) HIP_TRY(a.alloc(a_bytes));
+    if (h_b) HIP_TRY(b.alloc(b_bytes));
+    HIP_TRY(cc.alloc((size_t)(R > 0 ? R : 1) * 4));
+    HIP_TRY(st.alloc(8));
+    HIP_TRY(hipMemsetAsync(st.p, 0, 8, s));
+    if (transition) {
+        rc = ids ? vet_transition_entropy_ids(pl, (const int32_t*)id.p, U, T, (double*)ent.p, (int32_t*)a.p,
+                                              (int32_t*)b.p, (int32_t*)cc.p, (int32_t*)st.p, s)
+                 : vet_transition_entropy(pl, (const double*)mu.p, (const double*)mv.p, U, T, (double*)ent.p,
+                                          (int32_t*)a.p, (int32_t*)b.p, (int32_t*)cc.p, (int32_t*)st.p, s);
+    } else {
+        rc = ids ? vet_spatial_entropy_ids(pl, (const int32_t*)id.p, U, T, (double*)ent.p, (int32_t*)a.p,
+                                           (double*)b.p, (int32_t*)cc.p, (int32_t*)st.p, s)
+                 : vet_spatial_entropy(pl, (const double*)mu.p, (const double*)mv.p, U, T, (double*)ent.p,
+                                       (int32_t*)a.p, (double*)b.p, (int32_t*)cc.p, (int32_t*)st.p, s);
+    }
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    int32_t status[2] = {0, 0};
+    if (R > 0) {
+        HIP_TRY(hipMemcpyAsync(h_entropy, ent.p, (size_t)R * 8, hipMemcpyDeviceToHost, s));
+        if (h_a) HIP_TRY(hipMemcpyAsync(h_a, a.p, a_bytes, hipMemcpyDeviceToHost, s));
+        if (h_b) HIP_TRY(hipMemcpyAsync(h_b, b.p, b_bytes, hipMemcpyDeviceToHost, s));
+        if (h_c) HIP_TRY(hipMemcpyAsync(h_c, cc.p, (size_t)R * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(status, st.p, 8, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    if (status[0]) return fail(VET_ERR_RANGE, "Normalized coordinates must be between 0 and 1 (%d samples)", status[0]);
+    if (status[1])
+        return fail(VET_ERR_EMPTY, transition ? "%d frame pair(s) without a user present in both frames"
+                                              : "%d frame(s) without any user (Empty vector dictionary)", status[1]);
+    return VET_OK;
+}
+
+int vet_spatial_entropy_host(vet_plan* pl, const double* h_mu, const double* h_mv, const int32_t* h_ids, int U,
+                             int T, double* h_entropy, int32_t* h_assign, double* h_weights, int32_t* h_present) {
+    return run_host(pl, false, h_mu, h_mv, h_ids, U, T, h_entropy, h_assign, h_weights, h_present);
+}
+
+int vet_transition_entropy_host(vet_plan* pl, const double* h_mu, const double* h_mv, const int32_t* h_ids, int U,
+                                int T, double* h_entropy, int32_t* h_pairs, int32_t* h_srccount,
+                                int32_t* h_common) {
+    return run_host(pl, true, h_mu, h_mv, h_ids, U, T, h_entropy, h_pairs, h_srccount, h_common);
+}
+
+}  // extern "C"

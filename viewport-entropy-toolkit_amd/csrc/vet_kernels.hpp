@@ -1,0 +1,491 @@
+// vet_kernels.hpp — gfx950 (MI355X, CDNA4) device code of the viewport -> tile -> entropy path.
+//
+// Kernels (wave = 64 lanes everywhere):
+//   k_grid_dirs      axis tables -> rounded + normalised direction per pixel (py,px)
+//   k_nearest_lut    direction -> nearest lattice tile (FP64 arg-max of the normalised dot,
+//                    lowest index on ties), one LUT per lattice
+//   k_spatial        per frame: samples -> direction ids -> (weighted) tile histogram in LDS
+//                    (64-bit fixed point, order independent => bit-reproducible) -> Shannon
+//                    entropy; lane = tile, the wave walks the frame's users
+//   k_transition     per frame pair: (prior tile, current tile) pairs -> bucket statistics in
+//                    LDS (integer atomics + one small hash table) -> transition entropy
+//   k_finalize       mean over the plan's lattices
+//
+// No MFMA: there is no dense contraction on this path.  Reference citations are relative to
+// /root/reference/src/viewport_entropy_toolkit/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vet {
+
+constexpr int WAVE = 64;
+constexpr int QCAP = 128;                 // per-wave compaction queue entries
+constexpr unsigned EMPTY_KEY = 0xFFFFFFFFu;
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;   // butterfly: same value, same order, in every lane
+}
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+// numpy-scalar round(v, 6) == rint(v * 1e6) / 1e6   (data_types.py:213-215)
+__device__ __forceinline__ double round6(double v) { return rint(v * 1e6) / 1e6; }
+
+// ------------------------------------------------------------------------------------------
+// k_grid_dirs: Vector.from_spherical over the pixel grid (data_types.py:204-216) from the
+// host's axis tables, then the unit vector vector_angle_distance works with
+// (entropy_utils.py:55-58).  raw = rounded Vector xyz (parity hook), unit = raw / |raw|.
+// ------------------------------------------------------------------------------------------
+__global__ void k_grid_dirs(const double* __restrict__ lon_cos, const double* __restrict__ lon_sin,
+                            const double* __restrict__ lat_sin, const double* __restrict__ lat_cos,
+                            int W, int H, double* __restrict__ raw, double* __restrict__ unit) {
+    const long D = (long)(W + 1) * (H + 1);
+    for (long d = blockIdx.x * (long)blockDim.x + threadIdx.x; d < D; d += (long)gridDim.x * blockDim.x) {
+        const int py = (int)(d / (W + 1)), px = (int)(d % (W + 1));
+        const double sp = lat_sin[py];
+        const double x = round6(sp * lon_cos[px]);
+        const double y = round6(sp * lon_sin[px]);
+        const double z = round6(lat_cos[py]);
+        raw[3 * d + 0] = x; raw[3 * d + 1] = y; raw[3 * d + 2] = z;
+        const double len = sqrt(x * x + y * y + z * z);
+        unit[3 * d + 0] = x / len; unit[3 * d + 1] = y / len; unit[3 * d + 2] = z / len;
+    }
+}
+
+// explicit direction table: just the normalisation
+__global__ void k_unit_dirs(const double* __restrict__ raw, long D, double* __restrict__ unit) {
+    for (long d = blockIdx.x * (long)blockDim.x + threadIdx.x; d < D; d += (long)gridDim.x * blockDim.x) {
+        const double x = raw[3 * d], y = raw[3 * d + 1], z = raw[3 * d + 2];
+        const double len = sqrt(x * x + y * y + z * z);
+        unit[3 * d + 0] = x / len; unit[3 * d + 1] = y / len; unit[3 * d + 2] = z / len;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_nearest_lut: find_nearest_tile (entropy_utils.py:89-106) for every direction of the table.
+// arccos is monotone, so arg-min distance == arg-max cosine; '>' keeps the lowest index on
+// exact ties, as np.argmin does.  lane = direction, the tile walks through LDS (broadcast).
+// ------------------------------------------------------------------------------------------
+__global__ void k_nearest_lut(const double* __restrict__ unit, long D, const double* __restrict__ tiles,
+                              int n, uint16_t* __restrict__ nearest) {
+    extern __shared__ double s_tiles[];
+    for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) s_tiles[i] = tiles[i];
+    __syncthreads();
+    for (long d = blockIdx.x * (long)blockDim.x + threadIdx.x; d < D; d += (long)gridDim.x * blockDim.x) {
+        const double x = unit[3 * d], y = unit[3 * d + 1], z = unit[3 * d + 2];
+        double best = -2.0;
+        int bi = 0;
+        for (int t = 0; t < n; ++t) {
+            const double c = fma(z, s_tiles[3 * t + 2], fma(y, s_tiles[3 * t + 1], x * s_tiles[3 * t]));
+            if (c > best) { best = c; bi = t; }
+        }
+        nearest[d] = (uint16_t)bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// sample -> direction id
+// ------------------------------------------------------------------------------------------
+struct SampleSrc {
+    const double* mu;      // [T*U] or null
+    const double* mv;
+    const int32_t* ids;    // [T*U] or null
+    int W, H;
+    long n_dirs;
+};
+
+// returns direction id, -1 when absent; sets bad when a value is outside [0,1]
+// (normalize_to_pixel, data_utils.py:243-261: (v * dim).astype(int) truncates toward zero)
+template <bool FROM_IDS>
+__device__ __forceinline__ int sample_dir(const SampleSrc& s, long idx, bool& bad) {
+    if (FROM_IDS) {
+        const int id = s.ids[idx];
+        if (id >= s.n_dirs) { bad = true; return -1; }
+        return id < 0 ? -1 : id;
+    } else {
+        const double m = s.mu[idx], v = s.mv[idx];
+        if (m != m || v != v) return -1;                       // dropna()
+        if (!(m >= 0.0 && m <= 1.0 && v >= 0.0 && v <= 1.0)) { bad = true; return -1; }
+        const int px = (int)(m * (double)s.W);
+        const int py = (int)(v * (double)s.H);
+        return py * (s.W + 1) + px;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// FoV weight of one (direction, tile) pair from their cosine
+// calculate_tile_weights, entropy_utils.py:124-137:  d = arccos(clip(c)); if d < max:
+//   w = ((max - d) / max) ** power.  Returned in 64-bit fixed point (w * 2^s, rounded).
+// ------------------------------------------------------------------------------------------
+struct WeightCfg {
+    double max_ang;     // np.radians(fov/2)
+    double power;
+    int power_mode;     // 1: p == 1, 2: p == 2, 0: general pow()
+    double fx_scale;    // 2^s, s = 62 - ceil(log2(U))
+};
+
+__device__ __forceinline__ unsigned long long fov_weight_fx(double c, const WeightCfg& w) {
+    c = fmin(fmax(c, -1.0), 1.0);
+    const double d = acos(c);
+    if (!(d < w.max_ang)) return 0ull;
+    const double r = (w.max_ang - d) / w.max_ang;
+    double wt;
+    if (w.power_mode == 2) wt = r * r;
+    else if (w.power_mode == 1) wt = r;
+    else wt = pow(r, w.power);
+    return (unsigned long long)rint(wt * w.fx_scale);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_spatial — compute_spatial_entropy (entropy_utils.py:147-211) for FPW frames per workgroup.
+//
+// LDS (dynamic):   hist  u64 [FPW][n]        per-frame tile weight sums, fixed point
+//                  dirs  f64 [FPW][UC][3]    unit directions of the present users (compacted)
+//                  qc    f64 [NW][QCAP]      per-wave compaction queue: cosine
+//                  qt    u16 [NW][QCAP]                                 tile
+//                  cnt   i32 [FPW] chunk-present, [FPW] frame-present
+// Work item = (frame-local fl, tile group g of 64 tiles); wave w takes items w, w+NW, ...
+// In the sweep every lane owns one tile; for each present user the wave tests the FoV cone,
+// appends the hits to its queue (ballot + mbcnt, so the expensive acos/pow runs on full waves
+// only) and drains 64 entries at a time into the LDS histogram with ds_add_u64.
+// ------------------------------------------------------------------------------------------
+struct SpatialParams {
+    SampleSrc src;
+    int U, T;
+    const double* dir_unit;       // [n_dirs][3]
+    const uint16_t* nearest;      // [n_dirs] for this lattice
+    const double* tiles;          // [n][3] unit
+    int n;
+    int weighted;
+    double cos_cull;              // conservative: cos(max_ang) - eps (or < -1 when fov covers all)
+    WeightCfg wc;
+    double hmax;                  // -n*(1/n)*log2(1/n) (host, reference formula)
+    double* ent_k;                // [T]
+    int32_t* assign;              // [T*U] or null
+    double* weights;              // [T*n] or null
+    int32_t* present;             // [T] or null
+    int32_t* status;              // [2] or null
+    int FPW;                      // frames per workgroup
+    int G;                        // tile groups = ceil(n/64)
+    int UC;                       // users per LDS chunk
+};
+
+template <bool FROM_IDS, bool COMPACT>
+__global__ void k_spatial(const SpatialParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NW = blockDim.x >> 6;
+    unsigned long long* hist = (unsigned long long*)smem;                        // [FPW][n]
+    double* dirs = (double*)(hist + (size_t)p.FPW * p.n);                       // [FPW][UC][3]
+    double* qc = dirs + (size_t)p.FPW * p.UC * 3;                                // [NW][QCAP]
+    uint16_t* qt = (uint16_t*)(qc + (size_t)NW * QCAP);                          // [NW][QCAP]
+    int* cnt = (int*)(qt + (size_t)NW * QCAP);                                   // [2*FPW]
+    int* cnt_chunk = cnt;
+    int* cnt_frame = cnt + p.FPW;
+
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const long f0 = (long)blockIdx.x * p.FPW;
+    const int nf = (int)min((long)p.FPW, (long)p.T - f0);
+
+    for (int i = tid; i < p.FPW * p.n; i += blockDim.x) hist[i] = 0ull;
+    for (int i = tid; i < 2 * p.FPW; i += blockDim.x) cnt[i] = 0;
+    bool bad = false;
+    const unsigned long long one_fx = (unsigned long long)p.wc.fx_scale;
+
+    double* my_qc = qc + wv * QCAP;
+    uint16_t* my_qt = qt + wv * QCAP;
+
+    for (int u0 = 0; u0 < p.U; u0 += p.UC) {
+        const int uc = min(p.UC, p.U - u0);
+        __syncthreads();                      // hist/cnt init, or previous chunk fully consumed
+        for (int i = tid; i < p.FPW; i += blockDim.x) cnt_chunk[i] = 0;
+        __syncthreads();
+        // ---- prologue: samples -> direction ids -> unit directions in LDS, nearest tile out
+        for (int i = tid; i < nf * uc; i += blockDim.x) {
+            const int fl = i / uc, uu = i - fl * uc;
+            const long idx = (f0 + fl) * (long)p.U + u0 + uu;
+            const int id = sample_dir<FROM_IDS>(p.src, idx, bad);
+            int near = -1;
+            if (id >= 0) {
+                near = p.nearest[id];
+                if (p.weighted) {
+                    const int slot = atomicAdd(&cnt_chunk[fl], 1);
+                    double* dst = dirs + ((size_t)fl * p.UC + slot) * 3;
+                    dst[0] = p.dir_unit[3 * (long)id];
+                    dst[1] = p.dir_unit[3 * (long)id + 1];
+                    dst[2] = p.dir_unit[3 * (long)id + 2];
+                } else {
+                    // nearest tile takes weight 1.0 (entropy_utils.py:139-142)
+                    atomicAdd(&cnt_chunk[fl], 1);
+                    atomicAdd(&hist[(size_t)fl * p.n + near], one_fx);
+                }
+            }
+            if (p.assign) p.assign[idx] = near;
+        }
+        __syncthreads();
+        for (int i = tid; i < p.FPW; i += blockDim.x) cnt_frame[i] += cnt_chunk[i];
+        if (!p.weighted) continue;
+        // ---- sweep: lane = tile, walk the chunk's present users
+        for (int item = wv; item < nf * p.G; item += NW) {
+            const int fl = item / p.G, g = item - fl * p.G;
+            const int t = g * WAVE + lane;
+            const bool valid = t < p.n;
+            double tx = 0.0, ty = 0.0, tz = 0.0;
+            if (valid) { tx = p.tiles[3 * t]; ty = p.tiles[3 * t + 1]; tz = p.tiles[3 * t + 2]; }
+            const int nu = cnt_chunk[fl];
+            const double* dl = dirs + (size_t)fl * p.UC * 3;
+            unsigned long long* hrow = hist + (size_t)fl * p.n;
+            if (COMPACT) {
+                int qn = 0;
+                for (int j = 0; j < nu; ++j) {
+                    const double c = fma(dl[3 * j + 2], tz, fma(dl[3 * j + 1], ty, dl[3 * j] * tx));
+                    const bool hit = valid && (c > p.cos_cull);
+                    const unsigned long long mask = __ballot(hit);
+                    if (mask) {
+                        const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        if (hit) { my_qc[pos] = c; my_qt[pos] = (uint16_t)t; }
+                        qn += __popcll(mask);
+                        if (qn >= WAVE) {
+                            qn -= WAVE;
+                            __builtin_amdgcn_wave_barrier();
+                            const unsigned long long fx = fov_weight_fx(my_qc[qn + lane], p.wc);
+                            const int tt = my_qt[qn + lane];
+                            if (fx) atomicAdd(&hrow[tt], fx);
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < qn) {
+                    const unsigned long long fx = fov_weight_fx(my_qc[lane], p.wc);
+                    const int tt = my_qt[lane];
+                    if (fx) atomicAdd(&hrow[tt], fx);
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                unsigned long long acc = 0ull;
+                for (int j = 0; j < nu; ++j) {
+                    const double c = fma(dl[3 * j + 2], tz, fma(dl[3 * j + 1], ty, dl[3 * j] * tx));
+                    if (valid && c > p.cos_cull) acc += fov_weight_fx(c, p.wc);
+                }
+                if (valid && acc) atomicAdd(&hrow[t], acc);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- entropy per frame (entropy_utils.py:194-211); wave wv takes frames wv, wv+NW, ...
+    for (int fl = wv; fl < nf; fl += NW) {
+        const unsigned long long* hrow = hist + (size_t)fl * p.n;
+        unsigned long long tot = 0ull;
+        for (int t = lane; t < p.n; t += WAVE) tot += hrow[t];
+        tot = wave_sum(tot);
+        const double totd = (double)tot;
+        double h = 0.0;
+        for (int t = lane; t < p.n; t += WAVE) {
+            const unsigned long long v = hrow[t];
+            if (v) {
+                const double q = (double)v / totd;
+                h -= q * log2(q);
+            }
+            if (p.weights) p.weights[(f0 + fl) * (long)p.n + t] = (double)v / p.wc.fx_scale;
+        }
+        h = wave_sum(h);
+        if (lane == 0) {
+            const int np = cnt_frame[fl];
+            double hmax = p.hmax;
+            if (!p.weighted) {
+                // total_weight == number of present users (entropy_utils.py:201-206)
+                const double tw = (double)np;
+                if (!(tw > (double)p.n)) {
+                    const double mp = 1.0 / tw;
+                    hmax = -tw * mp * log2(mp);
+                }
+            }
+            double e = h / hmax;
+            if (np == 0) {
+                e = __builtin_nan("");
+                if (p.status) atomicAdd(&p.status[1], 1);
+            }
+            p.ent_k[f0 + fl] = e;
+            if (p.present) p.present[f0 + fl] = np;
+        }
+    }
+    if (p.status) {
+        const unsigned long long anybad = __ballot(bad);
+        if (anybad && lane == 0) atomicAdd(&p.status[0], (int)__popcll(anybad));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_transition — compute_transition_entropy (entropy_utils.py:213-332) for one frame pair per
+// workgroup.  For source tile p with m users in column order a_1 < ... < a_m the reference's
+// dict walk reduces to (pinned by oracle/vet_oracle.py):
+//   K = 1 + #distinct destinations among a_2..a_m        (a_1 sits alone in an int-keyed bucket)
+//   w = 1 if m == 1 else count among a_2..a_m of the destination whose first appearance is
+//       latest                                           (stale loop variable, :307-315)
+//   cell = -(m/N) * K * (w/m) * log2(w/m),  H = sum cell,  normalised by log2(n) if N > n else
+//   log2(N).
+// LDS: per tile  first_u, m, K-1, last_fu, w_last (u32 [n] each); hash of (p,c) buckets
+//      key/fu/cnt u32 [HS]; pc u32 [U] the packed pairs.  Integer atomics only, so the result
+//      does not depend on scheduling.
+// ------------------------------------------------------------------------------------------
+struct TransParams {
+    SampleSrc src;
+    int U, T;
+    const uint16_t* nearest;
+    int n;
+    double hmax;                  // n * -(1/n) * log2(1/n)
+    double* ent_k;                // [T-1]
+    int32_t* pairs;               // [(T-1)*U*2] or null
+    int32_t* srccount;            // [(T-1)*n] or null
+    int32_t* common;              // [T-1] or null
+    int32_t* status;
+    int HS;                       // hash slots (power of two >= 2*U)
+    int hs_shift;                 // 32 - log2(HS)
+};
+
+template <bool FROM_IDS>
+__global__ void k_transition(const TransParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* red = (double*)smem;                   // [16] per-wave partial sums
+    int* s_total = (int*)(red + 16);               // [2]
+    unsigned* first_u = (unsigned*)(s_total + 2);  // [n]
+    unsigned* m_cnt = first_u + p.n;               // [n]
+    unsigned* k_cnt = m_cnt + p.n;                 // [n]
+    unsigned* last_fu = k_cnt + p.n;               // [n]
+    unsigned* w_last = last_fu + p.n;              // [n]
+    unsigned* hkey = w_last + p.n;                 // [HS]
+    unsigned* hfu = hkey + p.HS;                   // [HS]
+    unsigned* hcnt = hfu + p.HS;                   // [HS]
+    unsigned* pc = hcnt + p.HS;                    // [U]
+
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id(), NW = blockDim.x >> 6;
+    const long r = blockIdx.x;                     // output row: frames r (prior) and r+1 (current)
+    for (int i = tid; i < p.n; i += blockDim.x) {
+        first_u[i] = 0xFFFFFFFFu; m_cnt[i] = 0; k_cnt[i] = 0; last_fu[i] = 0; w_last[i] = 0;
+    }
+    for (int i = tid; i < p.HS; i += blockDim.x) { hkey[i] = EMPTY_KEY; hfu[i] = 0xFFFFFFFFu; hcnt[i] = 0; }
+    if (tid == 0) s_total[0] = 0;
+    __syncthreads();
+
+    bool bad = false;
+    int mine = 0;
+    for (int u = tid; u < p.U; u += blockDim.x) {
+        const int ia = sample_dir<FROM_IDS>(p.src, r * (long)p.U + u, bad);
+        const int ib = sample_dir<FROM_IDS>(p.src, (r + 1) * (long)p.U + u, bad);
+        unsigned packed = EMPTY_KEY;
+        int pa = -1, cb = -1;
+        if (ia >= 0 && ib >= 0) {           // user present in both frames (entropy_utils.py:259-261)
+            pa = p.nearest[ia]; cb = p.nearest[ib];
+            packed = ((unsigned)pa << 16) | (unsigned)cb;
+            atomicMin(&first_u[pa], (unsigned)u);
+            atomicAdd(&m_cnt[pa], 1u);
+            ++mine;
+        }
+        pc[u] = packed;
+        if (p.pairs) {
+            p.pairs[(r * (long)p.U + u) * 2] = pa;
+            p.pairs[(r * (long)p.U + u) * 2 + 1] = cb;
+        }
+    }
+    mine = wave_sum(mine);
+    if (lane == 0 && mine) atomicAdd(&s_total[0], mine);
+    __syncthreads();
+    const int N = s_total[0];
+
+    // buckets of the non-first users of each source tile
+    for (int u = tid; u < p.U; u += blockDim.x) {
+        const unsigned key = pc[u];
+        if (key == EMPTY_KEY) continue;
+        if (first_u[key >> 16] == (unsigned)u) continue;
+        unsigned h = (key * 2654435761u) >> p.hs_shift;
+        for (;;) {
+            const unsigned prev = atomicCAS(&hkey[h], EMPTY_KEY, key);
+            if (prev == EMPTY_KEY || prev == key) break;
+            h = (h + 1) & (unsigned)(p.HS - 1);
+        }
+        atomicMin(&hfu[h], (unsigned)u);
+        atomicAdd(&hcnt[h], 1u);
+    }
+    __syncthreads();
+    for (int s = tid; s < p.HS; s += blockDim.x) {
+        const unsigned key = hkey[s];
+        if (key == EMPTY_KEY) continue;
+        atomicAdd(&k_cnt[key >> 16], 1u);
+        atomicMax(&last_fu[key >> 16], hfu[s]);
+    }
+    __syncthreads();
+    for (int s = tid; s < p.HS; s += blockDim.x) {
+        const unsigned key = hkey[s];
+        if (key == EMPTY_KEY) continue;
+        if (hfu[s] == last_fu[key >> 16]) w_last[key >> 16] = hcnt[s];
+    }
+    __syncthreads();
+
+    double h = 0.0;
+    for (int t = tid; t < p.n; t += blockDim.x) {
+        const unsigned m = m_cnt[t];
+        if (m) {
+            const unsigned K = 1u + k_cnt[t];
+            const unsigned w = (m == 1u) ? 1u : w_last[t];
+            const double q = (double)w / (double)m;
+            const double prop = (double)m / (double)N;
+            h += -prop * ((double)K * (q * log2(q)));
+        }
+        if (p.srccount) p.srccount[r * (long)p.n + t] = (int)m;
+    }
+    h = wave_sum(h);
+    if (lane == 0) red[wv] = h;
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < NW; ++i) tot += red[i];
+        double hmax = p.hmax;
+        if (!(N > p.n)) {
+            const double tp = 1.0 / (double)N;          // entropy_utils.py:322-327
+            hmax = (double)N * -tp * log2(tp);
+        }
+        double e = tot / hmax;
+        if (N == 0) {
+            e = __builtin_nan("");
+            if (p.status) atomicAdd(&p.status[1], 1);
+        }
+        p.ent_k[r] = e;
+        if (p.common) p.common[r] = N;
+    }
+    if (p.status) {
+        const unsigned long long anybad = __ballot(bad);
+        if (anybad && lane == 0) atomicAdd(&p.status[0], (int)__popcll(anybad));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_finalize: avg_entropy = (sum over lattices, in order) / K   (spatial_entropy.py:142-156)
+// ------------------------------------------------------------------------------------------
+__global__ void k_finalize(const double* __restrict__ ent_k, int K, long rows, double* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < rows; i += (long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += ent_k[(long)k * rows + i];
+        out[i] = s / (double)K;
+    }
+}
+
+}  // namespace vet

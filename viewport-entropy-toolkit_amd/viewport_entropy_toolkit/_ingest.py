@@ -1,0 +1,102 @@
+"""Dense, vectorised ingest: per-user CSV tracks -> frame-major ``mu[T][U]`` / ``mv[T][U]``.
+
+Same semantics as the reference's ``process_viewport_data`` + ``format_trajectory_data``
+(utilities/data_utils.py:289-410) without its per-row Python objects and O(T^2) list search:
+
+* rows with a NaN in time / 2dmu / 2dmv are dropped, time is shifted to start at 0;
+* any 2dmu / 2dmv outside [0, 1] fails the whole file; W and H must be even;
+* frame time = ``round(time, 1)``; the frame index is the FIRST-APPEARANCE order of the
+  rounded times while walking users in the given order (not sorted);
+* several rows of one user in the same frame: the last row wins;
+* a (frame, user) cell without a row is absent (NaN here, ``None`` in the reference).
+
+The arrays produced here are exactly what the C-ABI consumes; the quantisation to pixels,
+directions and tiles happens on the device.
+"""
+
+from __future__ import annotations
+
+from pathlib import Path
+from typing import List, Sequence, Tuple, Union
+
+import numpy as np
+import pandas as pd
+
+from .data_types import ValidationError
+
+
+def check_video_dimensions(width: int, height: int) -> None:
+    if width <= 0 or height <= 0:
+        raise ValidationError("Video dimensions must be positive")
+    if width % 2 != 0 or height % 2 != 0:
+        raise ValidationError("Video dimensions must be even numbers")
+
+
+def to_pixels(normalized: np.ndarray, dimension: int) -> np.ndarray:
+    """(v * dimension) truncated to int; v must lie in [0, 1]."""
+    normalized = np.asarray(normalized)
+    if np.any((normalized < 0) | (normalized > 1)):
+        raise ValidationError("Normalized coordinates must be between 0 and 1")
+    if dimension <= 0:
+        raise ValidationError("Dimension must be positive")
+    return (normalized * dimension).astype(int)
+
+
+def read_track(filepath: Union[str, Path], width: int, height: int) -> Tuple[pd.DataFrame, str]:
+    """One user's CSV -> cleaned DataFrame (time, 2dmu, 2dmv, pixel_x, pixel_y, lon, lat)."""
+    try:
+        filepath = Path(filepath)
+        if not filepath.exists():
+            raise FileNotFoundError(f"File not found: {filepath}")
+        data = pd.read_csv(filepath, usecols=["time", "2dmu", "2dmv"]).dropna()
+        if data.empty:
+            raise ValidationError(f"No valid data found in {filepath}")
+        data["time"] -= data["time"].min()
+        data["pixel_x"] = to_pixels(data["2dmu"].values, width)
+        data["pixel_y"] = to_pixels(data["2dmv"].values, height)
+        check_video_dimensions(width, height)
+        data["lon"] = (data["pixel_x"].to_numpy() / width) * 360 - 180
+        data["lat"] = 90 - (data["pixel_y"].to_numpy() / height) * 180
+        return data, filepath.stem
+    except Exception as e:  # noqa: BLE001 - the reference funnels every failure into ValidationError
+        raise ValidationError(f"Error processing viewport data: {str(e)}")
+
+
+def frame_keys(time: np.ndarray) -> np.ndarray:
+    """Integer identity of ``round(time, 1)`` (= rint(time*10); the float is key/10)."""
+    return np.rint(np.asarray(time, dtype=np.float64) * 10.0).astype(np.int64)
+
+
+def build_dense(tracks: Sequence[Tuple[np.ndarray, np.ndarray, np.ndarray]]):
+    """tracks: per user (time, mu, mv) already cleaned.  Returns (frame_times[T], mu[T,U], mv[T,U])."""
+    if not tracks:
+        raise ValidationError("No trajectory data provided")
+    known = np.empty(0, dtype=np.int64)           # frame keys in first-appearance order
+    per_user = []
+    for time, _, _ in tracks:
+        keys = frame_keys(time)
+        uniq, first = np.unique(keys, return_index=True)
+        uniq = uniq[np.argsort(first, kind="stable")]           # this user's first-appearance order
+        if len(known):
+            uniq = uniq[~np.isin(uniq, known)]
+        known = np.concatenate([known, uniq])
+        per_user.append(keys)
+    T, U = len(known), len(tracks)
+    order = np.argsort(known, kind="stable")
+    sorted_keys = known[order]
+    mu = np.full((T, U), np.nan)
+    mv = np.full((T, U), np.nan)
+    for u, ((_, a, b), keys) in enumerate(zip(tracks, per_user)):
+        frame = order[np.searchsorted(sorted_keys, keys)]
+        # last row of a frame wins: walk reversed, keep first occurrence
+        rev = frame[::-1]
+        _, idx = np.unique(rev, return_index=True)
+        rows = len(frame) - 1 - idx
+        mu[frame[rows], u] = np.asarray(a, dtype=np.float64)[rows]
+        mv[frame[rows], u] = np.asarray(b, dtype=np.float64)[rows]
+    return known.astype(np.float64) / 10.0, mu, mv
+
+
+def tracks_from_frames(trajectory_data: List[Tuple[str, pd.DataFrame]]):
+    return [(d["time"].to_numpy(dtype=np.float64), d["2dmu"].to_numpy(dtype=np.float64),
+             d["2dmv"].to_numpy(dtype=np.float64)) for _, d in trajectory_data]

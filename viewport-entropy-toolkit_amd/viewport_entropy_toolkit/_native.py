@@ -1,0 +1,276 @@
+"""ctypes binding of the HIP engine's C-ABI (include/vet.h, libvet_hip.so).
+
+This module is the only place the package touches native code.  It has no CPU fallback: if
+the shared library has not been built, or no gfx950 device is visible, every compute entry
+point raises ``NativeUnavailable`` with the reason.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _quantiser
+
+_PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("VET_HIP_LIBRARY", _PKG_DIR.parent / "lib" / "libvet_hip.so"))
+
+VET_OK, VET_ERR_INVALID, VET_ERR_DEVICE, VET_ERR_RANGE, VET_ERR_EMPTY, VET_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+KERNEL_IDS = {"k_grid_dirs": 0, "k_nearest_lut": 1, "k_spatial": 2, "k_transition": 3, "k_finalize": 4}
+
+
+class NativeUnavailable(RuntimeError):
+    """The HIP extension is missing or no MI355X is visible."""
+
+
+class NativeError(RuntimeError):
+    """A C-ABI call failed; ``code`` is the VET_ERR_* value."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+class _PlanDesc(C.Structure):
+    _fields_ = [
+        ("video_width", C.c_int), ("video_height", C.c_int),
+        ("h_lon_cos", C.c_void_p), ("h_lon_sin", C.c_void_p),
+        ("h_lat_sin", C.c_void_p), ("h_lat_cos", C.c_void_p),
+        ("h_dir_table", C.c_void_p), ("n_dirs", C.c_int64),
+        ("n_lattices", C.c_int), ("n_tiles", C.c_void_p),
+        ("h_tiles", C.c_void_p), ("h_max_entropy", C.c_void_p),
+        ("fov_angle", C.c_double), ("max_angular_distance", C.c_double),
+        ("power_factor", C.c_double), ("use_weight_distribution", C.c_int),
+    ]
+
+
+# name -> (restype, argtypes); also the list tests check against include/vet.h
+_P, _I, _I64, _D, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
+SIGNATURES = {
+    "vet_version": (_I, []),
+    "vet_last_error": (C.c_char_p, []),
+    "vet_device_count": (_I, []),
+    "vet_create": (_I, [_I, C.POINTER(_P)]),
+    "vet_destroy": (_I, [_P]),
+    "vet_synchronize": (_I, [_P]),
+    "vet_profile_enable": (_I, [_P, _I]),
+    "vet_profile_reset": (_I, [_P]),
+    "vet_profile_get": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_I64)]),
+    "vet_kernel_name": (C.c_char_p, [_I]),
+    "vet_malloc": (_I, [_P, _SZ, C.POINTER(_P)]),
+    "vet_free": (_I, [_P, _P]),
+    "vet_memcpy_h2d": (_I, [_P, _P, _P, _SZ]),
+    "vet_memcpy_d2h": (_I, [_P, _P, _P, _SZ]),
+    "vet_plan_create": (_I, [_P, C.POINTER(_PlanDesc), C.POINTER(_P)]),
+    "vet_plan_destroy": (_I, [_P]),
+    "vet_plan_n_dirs": (_I64, [_P]),
+    "vet_plan_read_dirs": (_I, [_P, _P]),
+    "vet_plan_read_nearest": (_I, [_P, _I, _P]),
+    "vet_spatial_entropy": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vet_spatial_entropy_ids": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vet_transition_entropy": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vet_transition_entropy_ids": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vet_spatial_entropy_host": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "vet_transition_entropy_host": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen libvet_hip.so and declare every prototype; raises NativeUnavailable."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not LIB_PATH.exists():
+            raise NativeUnavailable(
+                f"HIP extension not found at {LIB_PATH}. Build it with "
+                f"`make -C {_PKG_DIR.parent / 'csrc'}` (or __graft_entry__.build()); "
+                "this package has no CPU compute path.")
+        try:
+            lib = C.CDLL(str(LIB_PATH))
+        except OSError as e:  # missing ROCm runtime etc.
+            raise NativeUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+        return lib
+
+
+def _check(lib, rc: int):
+    if rc != VET_OK:
+        msg = lib.vet_last_error()
+        raise NativeError(rc, (msg or b"").decode("utf-8", "replace") or f"vet error {rc}")
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One device context (stream + scratch).  ``Engine.default()`` is per process."""
+
+    _default = None
+    _default_lock = threading.Lock()
+
+    def __init__(self, device_id: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.vet_create(device_id, C.byref(h))
+        if rc == VET_ERR_DEVICE:
+            raise NativeUnavailable((self.lib.vet_last_error() or b"").decode())
+        _check(self.lib, rc)
+        self.handle = h
+        self.device_id = device_id
+
+    @classmethod
+    def default(cls) -> "Engine":
+        with cls._default_lock:
+            if cls._default is None:
+                dev = int(os.environ.get("VET_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+                n = load_library().vet_device_count()
+                cls._default = cls(dev if 0 <= dev < max(n, 1) else 0)
+            return cls._default
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.vet_destroy(self.handle)
+            self.handle = None
+
+    def synchronize(self):
+        _check(self.lib, self.lib.vet_synchronize(self.handle))
+
+    # --- profiling -------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        _check(self.lib, self.lib.vet_profile_enable(self.handle, int(on)))
+
+    def profile_reset(self):
+        _check(self.lib, self.lib.vet_profile_reset(self.handle))
+
+    def profile_get(self, kernel: str):
+        ms, n = C.c_double(), C.c_int64()
+        _check(self.lib, self.lib.vet_profile_get(self.handle, KERNEL_IDS[kernel], C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+class Plan:
+    """Device tables of one analyzer configuration (quantiser, lattices, nearest LUTs)."""
+
+    def __init__(self, engine: Engine, tile_xyz: Sequence[np.ndarray], fov_angle: float, power_factor: float,
+                 use_weight_distribution: bool, video_width: int = 0, video_height: int = 0,
+                 dir_table: Optional[np.ndarray] = None):
+        self.engine = engine
+        self.lib = engine.lib
+        self.tiles = [np.ascontiguousarray(t, dtype=np.float64) for t in tile_xyz]
+        self.n_tiles = [len(t) for t in self.tiles]
+        self.weighted = bool(use_weight_distribution)
+        self.width, self.height = int(video_width), int(video_height)
+        d = _PlanDesc()
+        keep = []
+        if dir_table is None:
+            axes = _quantiser.axis_trig(self.width, self.height)
+            keep.extend(axes)
+            d.video_width, d.video_height = self.width, self.height
+            d.h_lon_cos, d.h_lon_sin, d.h_lat_sin, d.h_lat_cos = (a.ctypes.data for a in axes)
+        else:
+            tab = np.ascontiguousarray(dir_table, dtype=np.float64).reshape(-1, 3)
+            keep.append(tab)
+            d.h_dir_table, d.n_dirs = tab.ctypes.data, len(tab)
+        n_arr = np.asarray(self.n_tiles, dtype=np.int32)
+        ptrs = (C.c_void_p * len(self.tiles))(*[t.ctypes.data for t in self.tiles])
+        hmax = np.asarray([_quantiser.max_entropy(n) for n in self.n_tiles], dtype=np.float64)
+        keep.extend([n_arr, ptrs, hmax])
+        d.n_lattices = len(self.tiles)
+        d.n_tiles = n_arr.ctypes.data
+        d.h_tiles = C.cast(ptrs, C.c_void_p)
+        d.h_max_entropy = hmax.ctypes.data
+        d.fov_angle = float(fov_angle)
+        d.max_angular_distance = float(np.radians(fov_angle / 2.0))
+        d.power_factor = float(power_factor)
+        d.use_weight_distribution = int(self.weighted)
+        h = C.c_void_p()
+        _check(self.lib, self.lib.vet_plan_create(engine.handle, C.byref(d), C.byref(h)))
+        self.handle = h
+        self.n_dirs = int(self.lib.vet_plan_n_dirs(h))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.vet_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # plans are small; free device tables with the Python object
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # --- parity hooks ---------------------------------------------------------
+    def read_dirs(self) -> np.ndarray:
+        out = np.empty((self.n_dirs, 3), dtype=np.float64)
+        _check(self.lib, self.lib.vet_plan_read_dirs(self.handle, _ptr(out)))
+        return out
+
+    def read_nearest(self, lattice: int = 0) -> np.ndarray:
+        out = np.empty(self.n_dirs, dtype=np.int32)
+        _check(self.lib, self.lib.vet_plan_read_nearest(self.handle, lattice, _ptr(out)))
+        return out
+
+    # --- host-buffer runs (what the analyzers use) ---------------------------
+    @staticmethod
+    def _samples(mu, mv, ids):
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, dtype=np.int32)
+            return None, None, ids, ids.shape
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        mv = np.ascontiguousarray(mv, dtype=np.float64)
+        if mu.shape != mv.shape or mu.ndim != 2:
+            raise ValueError("mu and mv must be [n_frames, n_users] arrays of equal shape")
+        return mu, mv, None, mu.shape
+
+    def spatial(self, mu=None, mv=None, ids=None, want_assign=True, want_weights=False, check=True):
+        """Returns dict(entropy[T], assign[T,U]|None, weights[T,n0]|None, present[T], code)."""
+        mu, mv, ids, (T, U) = self._samples(mu, mv, ids)
+        ent = np.empty(T, dtype=np.float64)
+        assign = np.empty((T, U), dtype=np.int32) if want_assign else None
+        weights = np.empty((T, self.n_tiles[0]), dtype=np.float64) if want_weights else None
+        present = np.empty(T, dtype=np.int32)
+        rc = self.lib.vet_spatial_entropy_host(self.handle, _ptr(mu), _ptr(mv), _ptr(ids), U, T, _ptr(ent),
+                                               _ptr(assign), _ptr(weights), _ptr(present))
+        if rc not in (VET_OK, VET_ERR_EMPTY, VET_ERR_RANGE) or (check and rc != VET_OK):
+            _check(self.lib, rc)
+        return dict(entropy=ent, assign=assign, weights=weights, present=present, code=rc)
+
+    def transition(self, mu=None, mv=None, ids=None, want_pairs=True, want_srccount=False, check=True):
+        """Returns dict(entropy[T-1], pairs[T-1,U,2]|None, srccount[T-1,n0]|None, common[T-1], code)."""
+        mu, mv, ids, (T, U) = self._samples(mu, mv, ids)
+        R = max(T - 1, 0)
+        ent = np.empty(R, dtype=np.float64)
+        pairs = np.empty((R, U, 2), dtype=np.int32) if want_pairs else None
+        src = np.empty((R, self.n_tiles[0]), dtype=np.int32) if want_srccount else None
+        common = np.empty(R, dtype=np.int32)
+        rc = self.lib.vet_transition_entropy_host(self.handle, _ptr(mu), _ptr(mv), _ptr(ids), U, T, _ptr(ent),
+                                                  _ptr(pairs), _ptr(src), _ptr(common))
+        if rc not in (VET_OK, VET_ERR_EMPTY, VET_ERR_RANGE) or (check and rc != VET_OK):
+            _check(self.lib, rc)
+        return dict(entropy=ent, pairs=pairs, srccount=src, common=common, code=rc)
+
+    # --- device-pointer runs (inputs resident in HBM; asynchronous on ``stream``) ----
+    def spatial_device(self, d_mu: int, d_mv: int, n_users: int, n_frames: int, d_entropy: int, d_assign: int = 0,
+                       d_weights: int = 0, d_present: int = 0, d_status: int = 0, stream: int = 0):
+        _check(self.lib, self.lib.vet_spatial_entropy(self.handle, d_mu, d_mv, n_users, n_frames, d_entropy,
+                                                      d_assign or None, d_weights or None, d_present or None,
+                                                      d_status or None, stream or None))
+
+    def transition_device(self, d_mu: int, d_mv: int, n_users: int, n_frames: int, d_entropy: int, d_pairs: int = 0,
+                          d_srccount: int = 0, d_common: int = 0, d_status: int = 0, stream: int = 0):
+        _check(self.lib, self.lib.vet_transition_entropy(self.handle, d_mu, d_mv, n_users, n_frames, d_entropy,
+                                                         d_pairs or None, d_srccount or None, d_common or None,
+                                                         d_status or None, stream or None))

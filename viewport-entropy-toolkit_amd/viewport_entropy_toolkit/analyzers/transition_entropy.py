@@ -1,0 +1,51 @@
+"""TransitionEntropyAnalyzer: per-frame entropy of the (t-1 -> t) nearest-tile transitions of
+the users present in both frames (reference analyzers/transition_entropy.py:107-175 and
+utilities/entropy_utils.py:213-332), computed by the HIP engine in one call per video.
+Row 0 of the frame table only seeds the prior, so the result has T-1 rows."""
+
+from __future__ import annotations
+
+import logging
+
+import pandas as pd
+
+from .. import _native
+from ..data_types import ValidationError
+from .._results import TilePairs, TileWeights
+from ._base import _EntropyAnalyzerBase
+
+logger = logging.getLogger(__name__)
+
+
+class TransitionEntropyAnalyzer(_EntropyAnalyzerBase):
+    """Drop-in analyzer with the reference's result schema; ``tile_weights`` holds the user
+    count per source tile and ``tile_assignments`` the (prior, current) tile index pairs."""
+
+    _logger = logger
+
+    def compute_entropy(self) -> pd.DataFrame:
+        kind, times, a, b, names = self._samples()
+        try:
+            if kind == "grid":
+                res = self._get_plan().transition(mu=a, mv=b, want_pairs=True, want_srccount=True)
+            else:
+                plan = self._get_plan(dir_table=b)
+                try:
+                    res = plan.transition(ids=a, want_pairs=True, want_srccount=True)
+                finally:
+                    plan.close()
+        except _native.NativeError as e:
+            if e.code == _native.VET_ERR_RANGE:
+                raise ValidationError(str(e))
+            if e.code == _native.VET_ERR_EMPTY:
+                # the reference divides by the (zero) number of common users
+                raise ZeroDivisionError("float division by zero")
+            raise
+        tiles = self._fibonacci_vectors[self.config.tile_counts[0]]
+        self._entropy_results = pd.DataFrame({
+            "time": times[1:],
+            "entropy": res["entropy"],
+            "tile_weights": [TileWeights(tiles, row, as_int=True) for row in res["srccount"]],
+            "tile_assignments": [TilePairs(names, row) for row in res["pairs"]],
+        })
+        return self._entropy_results

@@ -1,0 +1,116 @@
+"""Entropy configuration and the operator-level entry points of the reference
+(utilities/entropy_utils.py:20-38, 89-144, 147-332), served by the HIP engine.
+
+Callers pass arbitrary ``Vector`` objects here, so each call builds a small explicit
+direction table and runs the same kernels as the analyzers through the ``*_ids`` C-ABI
+entry points.  For whole videos use the analyzers: they keep the device tables alive.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from ..data_types import Vector, ValidationError
+from .. import _native
+
+
+@dataclass
+class EntropyConfig:
+    """Field-of-view weighting parameters."""
+
+    fov_angle: float = 120.0
+    use_weight_distribution: bool = True
+    power_factor: float = 2.0
+
+    def __post_init__(self) -> None:
+        if not 0 < self.fov_angle <= 360:
+            raise ValidationError("FOV angle must be between 0 and 360 degrees")
+        if self.power_factor <= 0:
+            raise ValidationError("Power factor must be positive")
+
+
+def _xyz(vectors) -> np.ndarray:
+    return np.array([[v.x, v.y, v.z] for v in vectors], dtype=np.float64).reshape(-1, 3)
+
+
+def _plan_for(vectors: List[Vector], tile_centers: List[Vector], config: EntropyConfig) -> "_native.Plan":
+    return _native.Plan(_native.Engine.default(), [_xyz(tile_centers)], config.fov_angle, config.power_factor,
+                        config.use_weight_distribution, dir_table=_xyz(vectors))
+
+
+def find_nearest_tile(vector: Vector, tile_centers: List[Vector]) -> int:
+    """Index of the tile centre at the smallest angular distance (lowest index on ties)."""
+    plan = _plan_for([vector], tile_centers, EntropyConfig())
+    try:
+        return int(plan.read_nearest(0)[0])
+    finally:
+        plan.close()
+
+
+def calculate_tile_weights(vector: Vector, tile_centers: List[Vector], config: EntropyConfig) -> Dict[Vector, float]:
+    """FoV weights of one viewing direction: ((max - d) / max) ** power for tiles closer than
+    fov/2, or weight 1.0 on the nearest tile when the distribution is switched off."""
+    plan = _plan_for([vector], tile_centers, config)
+    try:
+        if not config.use_weight_distribution:
+            return {tile_centers[int(plan.read_nearest(0)[0])]: 1.0}
+        row = plan.spatial(ids=np.zeros((1, 1), dtype=np.int32), want_assign=False, want_weights=True)["weights"][0]
+        return {tile_centers[int(i)]: float(row[i]) for i in np.argsort(-row, kind="stable") if row[i] > 0}
+    finally:
+        plan.close()
+
+
+def compute_spatial_entropy(vector_dict: Dict[str, Vector], tile_centers: List[Vector],
+                            config: EntropyConfig) -> Tuple[float, Dict[Vector, float], Dict[str, int]]:
+    """Normalised Shannon entropy of one frame's tile weight distribution.
+
+    Returns (entropy, {tile Vector: summed weight}, {identifier: nearest tile index})."""
+    if not vector_dict:
+        raise ValidationError("Empty vector dictionary")
+    if not tile_centers:
+        raise ValidationError("No tile centers provided")
+    users = [(k, v) for k, v in vector_dict.items() if v is not None]
+    if not users:
+        if config.use_weight_distribution:
+            return 0.0 / _native._quantiser.max_entropy(len(tile_centers)), {}, {}
+        raise ZeroDivisionError("float division by zero")
+    plan = _plan_for([v for _, v in users], tile_centers, config)
+    try:
+        ids = np.arange(len(users), dtype=np.int32)[None, :]
+        res = plan.spatial(ids=ids, want_assign=True, want_weights=True)
+    finally:
+        plan.close()
+    row = res["weights"][0]
+    weights = {tile_centers[int(i)]: float(row[i]) for i in np.nonzero(row > 0)[0]}
+    assignments = {k: int(a) for (k, _), a in zip(users, res["assign"][0])}
+    return float(res["entropy"][0]), weights, assignments
+
+
+def compute_transition_entropy(prior_vector_dict: dict, current_vector_dict: dict, tile_centers: List[Vector],
+                               config: EntropyConfig, FOV_angle: float) -> Tuple[float, Dict[Vector, int], Dict[str, Tuple[int, int]]]:
+    """Normalised transition entropy between two frames over users present in both.
+
+    ``config`` and ``FOV_angle`` do not influence the value (as in the reference).
+    Returns (entropy, {source tile Vector: user count}, {identifier: (prior idx, current idx)})."""
+    if not prior_vector_dict or not current_vector_dict:
+        raise ValidationError("Empty vector dictionary")
+    if not tile_centers:
+        raise ValidationError("No tile centers provided")
+    users = [k for k in current_vector_dict if k in prior_vector_dict]
+    if not users:
+        raise ZeroDivisionError("float division by zero")
+    vecs = [prior_vector_dict[k] for k in users] + [current_vector_dict[k] for k in users]
+    plan = _plan_for(vecs, tile_centers, EntropyConfig())
+    try:
+        U = len(users)
+        ids = np.arange(2 * U, dtype=np.int32).reshape(2, U)
+        res = plan.transition(ids=ids, want_pairs=True, want_srccount=True)
+    finally:
+        plan.close()
+    src = res["srccount"][0]
+    weights = {tile_centers[int(i)]: int(src[i]) for i in np.nonzero(src > 0)[0]}
+    assignments = {k: (int(p), int(c)) for k, (p, c) in zip(users, res["pairs"][0])}
+    return float(res["entropy"][0]), weights, assignments
