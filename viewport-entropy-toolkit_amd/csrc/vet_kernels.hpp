@@ -294,10 +294,11 @@ __global__ void k_spatial(const SpatialParams p) {
     // ---- entropy per frame (entropy_utils.py:194-211); wave wv takes frames wv, wv+NW, ...
     for (int fl = wv; fl < nf; fl += NW) {
         const unsigned long long* hrow = hist + (size_t)fl * p.n;
-        unsigned long long tot = 0ull;
-        for (int t = lane; t < p.n; t += WAVE) tot += hrow[t];
-        tot = wave_sum(tot);
-        const double totd = (double)tot;
+        // total weight: up to U*n/4 in units of 2^-s, which does not fit 64 bits, so it is summed
+        // in FP64 (fixed lane order + butterfly => still a pure function of the histogram)
+        double totd = 0.0;
+        for (int t = lane; t < p.n; t += WAVE) totd += (double)hrow[t];
+        totd = wave_sum(totd);
         double h = 0.0;
         for (int t = lane; t < p.n; t += WAVE) {
             const unsigned long long v = hrow[t];
