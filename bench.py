@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — whole-job throughput of the viewport -> tile -> entropy hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload config3|config2|config4|config5]
+
+A "step" is one pass of the hot path (one C-ABI call: samples resident in HBM -> per-frame
+entropy + nearest-tile assignments in HBM) over one synthetic video per GPU.  N > 1 is launched
+by torch.distributed.run, one rank per GPU, one video per rank (weak scaling, no data-path
+collective); the per-video entropy series are collected on rank 0 with ONE RCCL gather per
+step.  Rank 0 prints one JSON line (contract in the task statement) carrying `roofline`
+(dominant kernel, hipEvent-timed on the launch stream inside the timed region) and, at N = 1,
+`cpu_baseline` (the C port of the reference path timed on this box's host cores on a bounded
+sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for _p in (str(ROOT), str(ROOT / "viewport-entropy-toolkit_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+WORKLOADS = {
+    # name: (users, frames, tile_counts, mode, weighted)      BASELINE.json configs[...]
+    "config2": (64, 3000, [50, 100, 200], "spatial", True),
+    "config3": (1024, 30000, [500], "spatial", True),
+    "config3u": (1024, 30000, [500], "spatial", False),     # nearest-tile (unweighted) histogram
+    "config4": (256, 10000, [50, 100, 200], "spatial", True),
+    "config5": (512, 10000, [200], "transition", True),
+}
+
+
+def synth_video(U, T, seed, video_id):
+    """SURVEY.md §8d generator, vectorised over users (one PCG64 stream per video)."""
+    rng = np.random.default_rng(seed + video_id * 10**6)
+    mu = np.mod(0.5 + np.cumsum(rng.normal(0.0, 0.01, (T, U)), axis=0), 1.0)
+    mv = np.clip(0.5 + np.cumsum(rng.normal(0.0, 0.005, (T, U)), axis=0), 0.0, 1.0)
+    return np.ascontiguousarray(mu), np.ascontiguousarray(mv)
+
+
+def cpu_baseline(mu, mv, tcs, mode, weighted, budget_s):
+    """C port of the reference path (oracle/vet_oracle.c), single thread, bounded sample."""
+    from oracle import c_port
+    c_port.load()
+    T, U = mu.shape
+    fn = (lambda a, b: c_port.spatial_series(a, b, 100, 200, tcs, use_weight_distribution=weighted)) \
+        if mode == "spatial" else (lambda a, b: c_port.transition_series(a, b, 100, 200, tcs))
+    probe = max(2, min(T, 4096 // max(U, 1) + 2))
+    t0 = time.perf_counter()
+    fn(mu[:probe], mv[:probe])
+    dt = time.perf_counter() - t0
+    frames = int(max(probe, min(T, probe * budget_s / max(dt, 1e-6))))
+    t0 = time.perf_counter()
+    fn(mu[:frames], mv[:frames])
+    dt = time.perf_counter() - t0
+    return {"value": frames * U / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"first {frames} of {T} frames x {U} users of the same workload, "
+                      f"oracle/vet_oracle.c (gcc -O2, scalar FP64), {dt:.1f} s",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    multi = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from viewport_entropy_toolkit import _native, _quantiser
+
+    U, T, tcs, mode, weighted = WORKLOADS[args.workload]
+    mu_h, mv_h = synth_video(U, T, args.seed, rank)
+    mu = torch.from_numpy(mu_h).to(dev)
+    mv = torch.from_numpy(mv_h).to(dev)
+    R = T if mode == "spatial" else T - 1
+    ent = torch.empty(R, dtype=torch.float64, device=dev)
+    # nearest-tile output of lattice 0: [T,U] int32 (spatial) / [(T-1),U,2] int32 (transition)
+    idx = torch.empty((T, U) if mode == "spatial" else (R, U, 2), dtype=torch.int32, device=dev)
+    status = torch.zeros(2, dtype=torch.int32, device=dev)
+    gathered = [torch.empty(R, dtype=torch.float64, device=dev) for _ in range(world)] if (multi and rank == 0) else None
+
+    eng = _native.Engine(local_rank)
+    t0 = time.perf_counter()
+    plan = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in tcs], 120.0, 2.0, weighted, 100, 200)
+    eng.synchronize()
+    plan_ms = (time.perf_counter() - t0) * 1e3
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        if mode == "spatial":
+            plan.spatial_device(mu.data_ptr(), mv.data_ptr(), U, T, ent.data_ptr(), d_assign=idx.data_ptr(),
+                                d_status=status.data_ptr(), stream=stream)
+        else:
+            plan.transition_device(mu.data_ptr(), mv.data_ptr(), U, T, ent.data_ptr(), d_pairs=idx.data_ptr(),
+                                   d_status=status.data_ptr(), stream=stream)
+        if multi:
+            dist.gather(ent, gathered, dst=0)
+
+    def fence():
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.profile_enable(True)
+    eng.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kname = "k_spatial" if mode == "spatial" else "k_transition"
+    k_ms, k_n = eng.profile_get(kname)
+    fin_ms, fin_n = eng.profile_get("k_finalize")
+    eng.profile_enable(False)
+
+    if multi:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert int(status.sum().item()) == 0, "engine flagged out-of-range samples or empty frames"
+    e_host = ent.cpu().numpy()
+    assert np.isfinite(e_host).all()
+
+    if rank == 0:
+        samples_per_step = U * T * world
+        ms_per_step = elapsed / args.steps * 1e3
+        # algorithmic bytes per k_* launch: 16 B in + 4 B (8 B transition) out per
+        # sample, 8 B entropy per frame; with K lattices the samples are re-read K times but the
+        # nearest-tile output is written once
+        K = len(tcs)
+        per_sample_out = 4 if mode == "spatial" else 8
+        launches_per_step = K
+        alg_bytes_step = (16 * K + per_sample_out) * U * T + 8 * R * K
+        alg_bytes_launch = alg_bytes_step / launches_per_step
+        avg_kernel_ms = k_ms / max(k_n, 1)
+        achieved = alg_bytes_launch / (avg_kernel_ms * 1e-3) / 1e9 if k_n else None
+        traffic = None
+        tf = ROOT / "profiles" / "pmc_traffic.json"
+        if tf.exists():
+            try:
+                traffic = json.loads(tf.read_text()).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "viewport samples/sec", "value": samples_per_step / (ms_per_step * 1e-3), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {world} video(s) x {U} users x {T} frames, "
+                                   f"tile_counts={tcs}, {mode}, "
+                                   f"use_weight_distribution={weighted}, fov=120, W=100, H=200",
+                       "users": U, "frames": T, "tile_counts": tcs, "mode": mode,
+                       "videos_per_gpu": 1, "parallelism": f"one video per GPU x{world}"},
+            "frames_per_s": R * world / (ms_per_step * 1e-3),
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes_launch,
+                         "avg_kernel_ms": avg_kernel_ms, "launches": k_n,
+                         "note": "weighted FoV histogram is FP64-VALU-bound (acos/pow per in-FoV tile), "
+                                 "not HBM-bound; see DESIGN.md" if (mode == "spatial" and weighted) else
+                                 "integer histogram path"},
+            "kernel_ms_per_step": {kname: k_ms / args.steps, "k_finalize": fin_ms / args.steps},
+            "plan_build_ms": plan_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(mu_h, mv_h, tcs, mode, weighted, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    plan.close()
+    if multi:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

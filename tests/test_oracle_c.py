@@ -1,0 +1,74 @@
+"""Pins the C restatement (oracle/vet_oracle.c, the cpu_baseline "port") against the golden
+vectors of the real reference and against the numpy oracle."""
+import numpy as np
+import pytest
+
+from oracle import c_port, vet_oracle as vo
+
+RTOL = 1e-9
+
+
+def _dense(g, tag):
+    cols = [str(c) for c in g[f"{tag}__columns"]]
+    order = [int(c[4:]) for c in cols]
+    tracks = [(g["time_in"][u], g["mu_in"][u], g["mv_in"][u]) for u in order]
+    return vo.format_trajectories(tracks)
+
+
+@pytest.mark.parametrize("tag,tcs,kw", [
+    ("w_tc50", [50], {}),
+    ("w_tc50_100_200", [50, 100, 200], {}),
+    ("u_tc20_50", [20, 50], dict(use_weight_distribution=False)),
+    ("w_tc50_p15", [50], dict(power_factor=1.5)),
+    ("w_tc100_fov200_p05", [100], dict(fov_angle=200.0, power_factor=0.5)),
+])
+def test_c_spatial_vs_reference(golden_dir, tag, tcs, kw):
+    g = np.load(golden_dir / "g4_spatial.npz")
+    _, mu, mv = _dense(g, tag)
+    ent, assign, weights = c_port.spatial_series(mu, mv, 100, 200, tcs, want_weights=True, **kw)
+    assert np.array_equal(assign, g[f"{tag}__assign"])
+    np.testing.assert_allclose(ent, g[f"{tag}__entropy"], rtol=RTOL, equal_nan=True)
+    fr = g[f"{tag}__weights_frames"]
+    np.testing.assert_allclose(weights[fr], g[f"{tag}__weights"], rtol=RTOL, atol=1e-15)
+
+
+@pytest.mark.parametrize("tag,tcs", [("tc200", [200]), ("tc20_50", [20, 50])])
+def test_c_transition_vs_reference(golden_dir, tag, tcs):
+    g = np.load(golden_dir / "g5_transition.npz")
+    _, mu, mv = _dense(g, tag)
+    ent, pairs = c_port.transition_series(mu, mv, 100, 200, tcs)
+    assert np.array_equal(pairs, g[f"{tag}__pairs"])
+    np.testing.assert_allclose(ent, g[f"{tag}__entropy"], rtol=RTOL, equal_nan=True)
+
+
+@pytest.mark.parametrize("tc", [20, 50])
+def test_c_dense_transition(golden_dir, tc):
+    g = np.load(golden_dir / "g8_dense_transition.npz")
+    px, py, present = g["px"], g["py"], g["present"]
+    mu = np.where(present, np.where(px == 100, 1.0, (px + 0.5) / 100.0), np.nan)
+    mv = np.where(present, np.where(py == 200, 1.0, (py + 0.5) / 200.0), np.nan)
+    ent, pairs = c_port.transition_series(mu, mv, 100, 200, [tc])
+    assert np.array_equal(pairs, g[f"tc{tc}__pairs"])
+    np.testing.assert_allclose(ent, g[f"tc{tc}__entropy"], rtol=RTOL, equal_nan=True)
+    for tag, uw in (("u", False), ("w", True)):
+        e, _, _ = c_port.spatial_series(mu, mv, 100, 200, [tc], use_weight_distribution=uw)
+        np.testing.assert_allclose(e, g[f"tc{tc}__spatial_{tag}"], rtol=RTOL, equal_nan=True)
+
+
+def test_c_vs_numpy_oracle_with_absent_users():
+    import importlib.util, sys
+    from pathlib import Path
+    p = Path(__file__).resolve().parent.parent / "viewport-entropy-toolkit_amd" / "viewport_entropy_toolkit" / "_synthetic.py"
+    spec = importlib.util.spec_from_file_location("_vet_synth_t", p)
+    synth = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(synth)
+    mu, mv = synth.random_walk_video(24, 120, base_seed=21, p_absent=0.2)
+    for uw in (True, False):
+        a = c_port.spatial_series(mu, mv, 100, 200, [50, 100], use_weight_distribution=uw)
+        b = vo.spatial_series(mu, mv, 100, 200, [50, 100], use_weight_distribution=uw)
+        assert np.array_equal(a[1], b[1])
+        np.testing.assert_allclose(a[0], b[0], rtol=RTOL, equal_nan=True)
+    a = c_port.transition_series(mu, mv, 100, 200, [50])
+    b = vo.transition_series(mu, mv, 100, 200, [50], closed_form=False)
+    assert np.array_equal(a[1], b[1])
+    np.testing.assert_allclose(a[0], b[0], rtol=RTOL, equal_nan=True)
