@@ -143,29 +143,33 @@ int grid_for(long work, int block, int n_cu) {
     return (int)b;
 }
 
-// fixed-point scale: sums of up to U weights in [0,1] must stay below 2^62
-double fx_scale_for(int U) {
-    int bits = 0;
-    while ((1L << bits) < (long)(U < 2 ? 2 : U)) ++bits;
-    return std::ldexp(1.0, 62 - bits);
-}
-
 struct Geometry {
-    int NW, FPW, G, UC;
+    int NW, FPW, G, UC, R;
     size_t lds;
 };
 
-// launch geometry of k_spatial for a lattice of n tiles and U users
+// launch geometry of the spatial kernels for a lattice of n tiles and U users
 int spatial_geometry(const vet_ctx* c, int n, int U, bool weighted, Geometry* g) {
-    g->G = (n + vet::WAVE - 1) / vet::WAVE;
+    if (!weighted) {
+        // k_spatial_u: one wave per frame in the entropy phase; keep >= 2048 samples per workgroup
+        g->R = 1; g->G = 1; g->UC = 0;
+        g->NW = 4;
+        g->FPW = U >= 1024 ? 2 : (U >= 256 ? 4 : 16);
+        while ((size_t)g->FPW * n * 4 > c->lds_max && g->FPW > 1) g->FPW /= 2;
+        g->lds = (size_t)g->FPW * n * 4;
+        if (g->lds > c->lds_max)
+            return fail(VET_ERR_UNSUPPORTED, "lattice of %d tiles does not fit the LDS histogram (%zu B)", n, g->lds);
+        return VET_OK;
+    }
+    g->R = n > vet::WAVE ? 2 : 1;
+    g->G = (n + vet::WAVE * g->R - 1) / (vet::WAVE * g->R);
     if (g->G >= 4) { g->NW = g->G > 16 ? 16 : g->G; g->FPW = 1; }
     else { g->NW = 4; g->FPW = 4 / g->G; }
-    if (!weighted) { g->NW = 4; g->FPW = U >= 256 ? 1 : (U >= 64 ? 4 : 16); }
     g->UC = U < 1024 ? U : 1024;
     auto lds_of = [&](int fpw, int uc) {
         size_t b = (size_t)fpw * n * 8;
         b += (size_t)fpw * uc * 24;
-        b += (size_t)g->NW * vet::QCAP * (8 + 2);
+        b += (size_t)g->NW * vet::WAVE * (g->R + 1) * (8 + 2);
         b += (size_t)2 * fpw * 4 + 64;
         return b;
     };
@@ -175,6 +179,22 @@ int spatial_geometry(const vet_ctx* c, int n, int U, bool weighted, Geometry* g)
     if (g->lds > c->lds_max)
         return fail(VET_ERR_UNSUPPORTED, "lattice of %d tiles does not fit the LDS histogram (%zu B)", n, g->lds);
     return VET_OK;
+}
+
+// weight-evaluation variant of k_spatial_w (see fov_weight_fx)
+int weight_mode(const vet_plan* pl) {
+    const bool fast_acos = pl->max_ang <= 1.0471975511965979;   // fov <= 120 deg: z <= 0.2502
+    if (fast_acos && pl->power == 2.0) return 1;
+    if (fast_acos && pl->power == 1.0) return 2;
+    return 0;
+}
+
+template <bool FROM_IDS>
+const void* spatial_w_kernel(int wmode, int R) {
+#define VET_PICK(W, RR) if (wmode == W && R == RR) return (const void*)vet::k_spatial_w<FROM_IDS, W, RR>
+    VET_PICK(0, 1); VET_PICK(0, 2); VET_PICK(1, 1); VET_PICK(1, 2); VET_PICK(2, 1); VET_PICK(2, 2);
+#undef VET_PICK
+    return nullptr;
 }
 
 template <bool FROM_IDS>
@@ -188,6 +208,8 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         if (rc) return rc;
         ent_k = (double*)c->ws;
     }
+    int ubits = 0;
+    while ((1L << ubits) < (long)U) ++ubits;
     for (int k = 0; k < K; ++k) {
         const Lattice& L = pl->lat[k];
         Geometry g;
@@ -200,12 +222,11 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         p.nearest = L.d_nearest;
         p.tiles = L.d_tiles;
         p.n = L.n;
-        p.weighted = pl->weighted;
         p.cos_cull = pl->cos_cull;
         p.wc.max_ang = pl->max_ang;
+        p.wc.inv_max = 1.0 / pl->max_ang;
         p.wc.power = pl->power;
-        p.wc.power_mode = pl->power == 2.0 ? 2 : (pl->power == 1.0 ? 1 : 0);
-        p.wc.fx_scale = fx_scale_for(U);
+        p.wc.shift = ubits > 10 ? ubits - 10 : 0;   // per-tile sums of U weights stay below 2^62
         p.hmax = L.hmax;
         p.ent_k = ent_k + (size_t)k * T;
         p.assign = k == 0 ? d_assign : nullptr;
@@ -214,9 +235,11 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         p.status = k == 0 ? d_status : nullptr;
         p.FPW = g.FPW; p.G = g.G; p.UC = g.UC;
         const int blocks = (T + g.FPW - 1) / g.FPW;
+        const void* fn = pl->weighted ? spatial_w_kernel<FROM_IDS>(weight_mode(pl), g.R)
+                                      : (const void*)vet::k_spatial_u<FROM_IDS>;
+        void* args[] = {(void*)&p};
         ProfScope ps(c, s, KID_SPATIAL);
-        hipLaunchKernelGGL((vet::k_spatial<FROM_IDS, true>), dim3(blocks), dim3(g.NW * vet::WAVE), g.lds, s, p);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipLaunchKernel(fn, dim3(blocks), dim3(g.NW * vet::WAVE), args, g.lds, s));
     }
     if (K > 1) {
         ProfScope ps(c, s, KID_FINALIZE);
@@ -473,8 +496,13 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
     }
     PLAN_TRY(hipStreamSynchronize(s));
     // the run kernels may need more than the default 64 KiB of dynamic LDS
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    for (int wm = 0; wm < 3; ++wm)
+        for (int R = 1; R <= 2; ++R) {
+            PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<false>(wm, R), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+            PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<true>(wm, R), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+        }
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_transition<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
 #undef PLAN_TRY

@@ -20,7 +20,6 @@
 namespace vet {
 
 constexpr int WAVE = 64;
-constexpr int QCAP = 128;                 // per-wave compaction queue entries
 constexpr unsigned EMPTY_KEY = 0xFFFFFFFFu;
 
 // ------------------------------------------------------------------------------------------
@@ -132,39 +131,77 @@ __device__ __forceinline__ int sample_dir(const SampleSrc& s, long idx, bool& ba
 // ------------------------------------------------------------------------------------------
 // FoV weight of one (direction, tile) pair from their cosine
 // calculate_tile_weights, entropy_utils.py:124-137:  d = arccos(clip(c)); if d < max:
-//   w = ((max - d) / max) ** power.  Returned in 64-bit fixed point (w * 2^s, rounded).
+//   w = ((max - d) / max) ** power.  Returned in 64-bit fixed point: w * 2^(52 - shift).
 // ------------------------------------------------------------------------------------------
 struct WeightCfg {
     double max_ang;     // np.radians(fov/2)
+    double inv_max;     // 1 / max_ang
     double power;
-    int power_mode;     // 1: p == 1, 2: p == 2, 0: general pow()
-    double fx_scale;    // 2^s, s = 62 - ceil(log2(U))
+    int shift;          // fixed point = 2^(52-shift); shift = max(0, ceil(log2 U) - 10)
 };
 
+// WMODE: 0 generic (ocml acos, pow)   1 fast acos, power == 2   2 fast acos, power == 1
+// The fast acos needs max_ang <= 60 deg (fov <= 120): then c >= 0.5 - 1e-9 and
+//   theta = 2 asin(s), s = sqrt(z), z = (1 - c)/2 <= 0.2502,
+//   asin(s) = s + s z P(z), P of degree 9 fitted on [0, 0.2502]: |d theta| / theta < 2e-14.
+__device__ __forceinline__ double fast_theta(double c) {
+    const double z = fmax((1.0 - c) * 0.5, 1e-300);
+    // sqrt(z): hardware rsq seed, one Goldschmidt step and one residual correction
+    const double y = __builtin_amdgcn_rsq(z);
+    double s = z * y, h = 0.5 * y;
+    const double e = fma(-h, s, 0.5);
+    s = fma(s, e, s);
+    h = fma(h, e, h);
+    s = fma(fma(-s, s, z), h, s);
+    double P = 2.80476016723745745e-02;
+    P = fma(P, z, -3.09562448984870928e-03);
+    P = fma(P, z, 1.57475990547630423e-02);
+    P = fma(P, z, 1.31700206864407612e-02);
+    P = fma(P, z, 1.74440881411108591e-02);
+    P = fma(P, z, 2.23658455433679397e-02);
+    P = fma(P, z, 3.03821932887589595e-02);
+    P = fma(P, z, 4.46428521871264916e-02);
+    P = fma(P, z, 7.50000000381451232e-02);
+    P = fma(P, z, 1.66666666666618335e-01);
+    const double a = fma(s * z, P, s);
+    return a + a;
+}
+
+// w in [0, 1] -> round(w * 2^52) through the mantissa of 1 + w, then >> shift
+__device__ __forceinline__ unsigned long long unit_to_fx(double w, int shift) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(1.0 + w);
+    return (bits - 0x3FF0000000000000ull) >> shift;
+}
+
+template <int WMODE>
 __device__ __forceinline__ unsigned long long fov_weight_fx(double c, const WeightCfg& w) {
-    c = fmin(fmax(c, -1.0), 1.0);
-    const double d = acos(c);
-    if (!(d < w.max_ang)) return 0ull;
-    const double r = (w.max_ang - d) / w.max_ang;
-    double wt;
-    if (w.power_mode == 2) wt = r * r;
-    else if (w.power_mode == 1) wt = r;
-    else wt = pow(r, w.power);
-    return (unsigned long long)rint(wt * w.fx_scale);
+    if (WMODE == 0) {
+        c = fmin(fmax(c, -1.0), 1.0);
+        const double d = acos(c);
+        if (!(d < w.max_ang)) return 0ull;
+        const double r = (w.max_ang - d) / w.max_ang;
+        return unit_to_fx(pow(r, w.power), w.shift);
+    } else {
+        const double r = fmax((w.max_ang - fast_theta(c)) * w.inv_max, 0.0);   // 0 <=> not d < max
+        return unit_to_fx(WMODE == 1 ? r * r : r, w.shift);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
-// k_spatial — compute_spatial_entropy (entropy_utils.py:147-211) for FPW frames per workgroup.
+// k_spatial_w — compute_spatial_entropy (entropy_utils.py:147-211), FoV-weighted mode, for FPW
+// frames per workgroup.
 //
 // LDS (dynamic):   hist  u64 [FPW][n]        per-frame tile weight sums, fixed point
 //                  dirs  f64 [FPW][UC][3]    unit directions of the present users (compacted)
-//                  qc    f64 [NW][QCAP]      per-wave compaction queue: cosine
-//                  qt    u16 [NW][QCAP]                                 tile
+//                  qc    f64 [NW][64(R+1)]   per-wave compaction queue: cosine
+//                  qt    u16 [NW][64(R+1)]                              tile
 //                  cnt   i32 [FPW] chunk-present, [FPW] frame-present
-// Work item = (frame-local fl, tile group g of 64 tiles); wave w takes items w, w+NW, ...
-// In the sweep every lane owns one tile; for each present user the wave tests the FoV cone,
-// appends the hits to its queue (ballot + mbcnt, so the expensive acos/pow runs on full waves
-// only) and drains 64 entries at a time into the LDS histogram with ds_add_u64.
+// Work item = (frame-local fl, tile group g of 64*R tiles); wave w takes items w, w+NW, ...
+// In the sweep every lane owns R tiles (coordinates in registers); for each present user (LDS
+// broadcast read) the wave tests the FoV cone with an FP64 dot product, appends the hits to its
+// queue (ballot + mbcnt, so the acos/pow part runs on full waves only) and drains 64 entries at a
+// time into the LDS histogram with ds_add_u64.  Integer adds commute, so the histogram — and with
+// it the entropy — does not depend on scheduling or on the order of users.
 // ------------------------------------------------------------------------------------------
 struct SpatialParams {
     SampleSrc src;
@@ -173,7 +210,6 @@ struct SpatialParams {
     const uint16_t* nearest;      // [n_dirs] for this lattice
     const double* tiles;          // [n][3] unit
     int n;
-    int weighted;
     double cos_cull;              // conservative: cos(max_ang) - eps (or < -1 when fov covers all)
     WeightCfg wc;
     double hmax;                  // -n*(1/n)*log2(1/n) (host, reference formula)
@@ -183,33 +219,31 @@ struct SpatialParams {
     int32_t* present;             // [T] or null
     int32_t* status;              // [2] or null
     int FPW;                      // frames per workgroup
-    int G;                        // tile groups = ceil(n/64)
+    int G;                        // tile groups per frame = ceil(n / (64*R))
     int UC;                       // users per LDS chunk
 };
 
-template <bool FROM_IDS, bool COMPACT>
-__global__ void k_spatial(const SpatialParams p) {
+template <bool FROM_IDS, int WMODE, int R>
+__global__ void k_spatial_w(const SpatialParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int QC = WAVE * (R + 1);                                          // queue capacity
     const int NW = blockDim.x >> 6;
     unsigned long long* hist = (unsigned long long*)smem;                        // [FPW][n]
     double* dirs = (double*)(hist + (size_t)p.FPW * p.n);                       // [FPW][UC][3]
-    double* qc = dirs + (size_t)p.FPW * p.UC * 3;                                // [NW][QCAP]
-    uint16_t* qt = (uint16_t*)(qc + (size_t)NW * QCAP);                          // [NW][QCAP]
-    int* cnt = (int*)(qt + (size_t)NW * QCAP);                                   // [2*FPW]
-    int* cnt_chunk = cnt;
-    int* cnt_frame = cnt + p.FPW;
+    double* qc = dirs + (size_t)p.FPW * p.UC * 3;                                // [NW][QC]
+    uint16_t* qt = (uint16_t*)(qc + (size_t)NW * QC);                            // [NW][QC]
+    int* cnt_chunk = (int*)(qt + (size_t)NW * QC);                               // [FPW]
+    int* cnt_frame = cnt_chunk + p.FPW;                                          // [FPW]
 
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const long f0 = (long)blockIdx.x * p.FPW;
     const int nf = (int)min((long)p.FPW, (long)p.T - f0);
 
     for (int i = tid; i < p.FPW * p.n; i += blockDim.x) hist[i] = 0ull;
-    for (int i = tid; i < 2 * p.FPW; i += blockDim.x) cnt[i] = 0;
+    for (int i = tid; i < 2 * p.FPW; i += blockDim.x) cnt_chunk[i] = 0;
     bool bad = false;
-    const unsigned long long one_fx = (unsigned long long)p.wc.fx_scale;
-
-    double* my_qc = qc + wv * QCAP;
-    uint16_t* my_qt = qt + wv * QCAP;
+    double* my_qc = qc + wv * QC;
+    uint16_t* my_qt = qt + wv * QC;
 
     for (int u0 = 0; u0 < p.U; u0 += p.UC) {
         const int uc = min(p.UC, p.U - u0);
@@ -221,77 +255,71 @@ __global__ void k_spatial(const SpatialParams p) {
             const int fl = i / uc, uu = i - fl * uc;
             const long idx = (f0 + fl) * (long)p.U + u0 + uu;
             const int id = sample_dir<FROM_IDS>(p.src, idx, bad);
-            int near = -1;
             if (id >= 0) {
-                near = p.nearest[id];
-                if (p.weighted) {
-                    const int slot = atomicAdd(&cnt_chunk[fl], 1);
-                    double* dst = dirs + ((size_t)fl * p.UC + slot) * 3;
-                    dst[0] = p.dir_unit[3 * (long)id];
-                    dst[1] = p.dir_unit[3 * (long)id + 1];
-                    dst[2] = p.dir_unit[3 * (long)id + 2];
-                } else {
-                    // nearest tile takes weight 1.0 (entropy_utils.py:139-142)
-                    atomicAdd(&cnt_chunk[fl], 1);
-                    atomicAdd(&hist[(size_t)fl * p.n + near], one_fx);
-                }
+                const int slot = atomicAdd(&cnt_chunk[fl], 1);
+                double* dst = dirs + ((size_t)fl * p.UC + slot) * 3;
+                dst[0] = p.dir_unit[3 * (long)id];
+                dst[1] = p.dir_unit[3 * (long)id + 1];
+                dst[2] = p.dir_unit[3 * (long)id + 2];
             }
-            if (p.assign) p.assign[idx] = near;
+            if (p.assign) p.assign[idx] = id >= 0 ? (int)p.nearest[id] : -1;
         }
         __syncthreads();
         for (int i = tid; i < p.FPW; i += blockDim.x) cnt_frame[i] += cnt_chunk[i];
-        if (!p.weighted) continue;
-        // ---- sweep: lane = tile, walk the chunk's present users
+        // ---- sweep: lane = R tiles, walk the chunk's present users
         for (int item = wv; item < nf * p.G; item += NW) {
             const int fl = item / p.G, g = item - fl * p.G;
-            const int t = g * WAVE + lane;
-            const bool valid = t < p.n;
-            double tx = 0.0, ty = 0.0, tz = 0.0;
-            if (valid) { tx = p.tiles[3 * t]; ty = p.tiles[3 * t + 1]; tz = p.tiles[3 * t + 2]; }
-            const int nu = cnt_chunk[fl];
+            double tx[R], ty[R], tz[R];
+            int tt[R];
+            bool valid[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                tt[r] = (g * R + r) * WAVE + lane;
+                valid[r] = tt[r] < p.n;
+                const int ts = valid[r] ? tt[r] : 0;
+                tx[r] = p.tiles[3 * ts]; ty[r] = p.tiles[3 * ts + 1]; tz[r] = p.tiles[3 * ts + 2];
+            }
+            const int nu = __builtin_amdgcn_readfirstlane(cnt_chunk[fl]);
             const double* dl = dirs + (size_t)fl * p.UC * 3;
             unsigned long long* hrow = hist + (size_t)fl * p.n;
-            if (COMPACT) {
-                int qn = 0;
-                for (int j = 0; j < nu; ++j) {
-                    const double c = fma(dl[3 * j + 2], tz, fma(dl[3 * j + 1], ty, dl[3 * j] * tx));
-                    const bool hit = valid && (c > p.cos_cull);
+            int qn = 0;
+            for (int j = 0; j < nu; ++j) {
+                const double dx = dl[3 * j], dy = dl[3 * j + 1], dz = dl[3 * j + 2];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double c = fma(dz, tz[r], fma(dy, ty[r], dx * tx[r]));
+                    const bool hit = valid[r] && (c > p.cos_cull);
                     const unsigned long long mask = __ballot(hit);
-                    if (mask) {
+                    if (hit) {
                         const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                              __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                        if (hit) { my_qc[pos] = c; my_qt[pos] = (uint16_t)t; }
-                        qn += __popcll(mask);
-                        if (qn >= WAVE) {
-                            qn -= WAVE;
-                            __builtin_amdgcn_wave_barrier();
-                            const unsigned long long fx = fov_weight_fx(my_qc[qn + lane], p.wc);
-                            const int tt = my_qt[qn + lane];
-                            if (fx) atomicAdd(&hrow[tt], fx);
-                            __builtin_amdgcn_wave_barrier();
-                        }
+                        my_qc[pos] = c;
+                        my_qt[pos] = (uint16_t)tt[r];
                     }
+                    qn += __popcll(mask);
                 }
-                __builtin_amdgcn_wave_barrier();
-                if (lane < qn) {
-                    const unsigned long long fx = fov_weight_fx(my_qc[lane], p.wc);
-                    const int tt = my_qt[lane];
-                    if (fx) atomicAdd(&hrow[tt], fx);
+                while (qn >= WAVE) {
+                    qn -= WAVE;
+                    __builtin_amdgcn_wave_barrier();
+                    const unsigned long long fx = fov_weight_fx<WMODE>(my_qc[qn + lane], p.wc);
+                    const int t = my_qt[qn + lane];
+                    if (fx) atomicAdd(&hrow[t], fx);
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_wave_barrier();
-            } else {
-                unsigned long long acc = 0ull;
-                for (int j = 0; j < nu; ++j) {
-                    const double c = fma(dl[3 * j + 2], tz, fma(dl[3 * j + 1], ty, dl[3 * j] * tx));
-                    if (valid && c > p.cos_cull) acc += fov_weight_fx(c, p.wc);
-                }
-                if (valid && acc) atomicAdd(&hrow[t], acc);
             }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < qn) {
+                const unsigned long long fx = fov_weight_fx<WMODE>(my_qc[lane], p.wc);
+                const int t = my_qt[lane];
+                if (fx) atomicAdd(&hrow[t], fx);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
 
     // ---- entropy per frame (entropy_utils.py:194-211); wave wv takes frames wv, wv+NW, ...
+    const double fx_scale = (double)(1ull << (52 - p.wc.shift));
     for (int fl = wv; fl < nf; fl += NW) {
         const unsigned long long* hrow = hist + (size_t)fl * p.n;
         // total weight: up to U*n/4 in units of 2^-s, which does not fit 64 bits, so it is summed
@@ -306,19 +334,76 @@ __global__ void k_spatial(const SpatialParams p) {
                 const double q = (double)v / totd;
                 h -= q * log2(q);
             }
-            if (p.weights) p.weights[(f0 + fl) * (long)p.n + t] = (double)v / p.wc.fx_scale;
+            if (p.weights) p.weights[(f0 + fl) * (long)p.n + t] = (double)v / fx_scale;
         }
         h = wave_sum(h);
         if (lane == 0) {
             const int np = cnt_frame[fl];
-            double hmax = p.hmax;
-            if (!p.weighted) {
-                // total_weight == number of present users (entropy_utils.py:201-206)
-                const double tw = (double)np;
-                if (!(tw > (double)p.n)) {
-                    const double mp = 1.0 / tw;
-                    hmax = -tw * mp * log2(mp);
-                }
+            double e = h / p.hmax;
+            if (np == 0) {
+                e = __builtin_nan("");
+                if (p.status) atomicAdd(&p.status[1], 1);
+            }
+            p.ent_k[f0 + fl] = e;
+            if (p.present) p.present[f0 + fl] = np;
+        }
+    }
+    if (p.status) {
+        const unsigned long long anybad = __ballot(bad);
+        if (anybad && lane == 0) atomicAdd(&p.status[0], (int)__popcll(anybad));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_spatial_u — the same entropy with use_weight_distribution = False: every present user adds
+// weight 1.0 to its nearest tile (entropy_utils.py:139-142), so the frame histogram is an integer
+// count per tile and the path is a pure stream: 16 B in, LUT gather, 4 B out per sample.
+// LDS: cnt u32 [FPW][n].  Wave w owns frames w, w+NW, ... of the workgroup's FPW frames.
+// ------------------------------------------------------------------------------------------
+template <bool FROM_IDS>
+__global__ void k_spatial_u(const SpatialParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* cnt = (unsigned*)smem;                                             // [FPW][n]
+    const int NW = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const long f0 = (long)blockIdx.x * p.FPW;
+    const int nf = (int)min((long)p.FPW, (long)p.T - f0);
+    for (int i = tid; i < p.FPW * p.n; i += blockDim.x) cnt[i] = 0u;
+    __syncthreads();
+    bool bad = false;
+    for (long i = tid; i < (long)nf * p.U; i += blockDim.x) {
+        const int fl = (int)(i / p.U);
+        const long idx = f0 * (long)p.U + i;
+        const int id = sample_dir<FROM_IDS>(p.src, idx, bad);
+        int near = -1;
+        if (id >= 0) {
+            near = p.nearest[id];
+            atomicAdd(&cnt[(size_t)fl * p.n + near], 1u);
+        }
+        if (p.assign) p.assign[idx] = near;
+    }
+    __syncthreads();
+    for (int fl = wv; fl < nf; fl += NW) {
+        const unsigned* row = cnt + (size_t)fl * p.n;
+        int np = 0;
+        for (int t = lane; t < p.n; t += WAVE) np += (int)row[t];
+        np = wave_sum(np);
+        const double tw = (double)np;             // total_weight == number of present users
+        double h = 0.0;
+        for (int t = lane; t < p.n; t += WAVE) {
+            const unsigned v = row[t];
+            if (v) {
+                const double q = (double)v / tw;
+                h -= q * log2(q);
+            }
+            if (p.weights) p.weights[(f0 + fl) * (long)p.n + t] = (double)v;
+        }
+        h = wave_sum(h);
+        if (lane == 0) {
+            double hmax = p.hmax;                  // entropy_utils.py:201-206
+            if (!(tw > (double)p.n)) {
+                const double mp = 1.0 / tw;
+                hmax = -tw * mp * log2(mp);
             }
             double e = h / hmax;
             if (np == 0) {
