@@ -59,7 +59,8 @@ int vet_synchronize(vet_ctx *ctx);
 /* Per-kernel timing with hipEvents on the launch stream (bench.py's roofline leg). */
 int vet_profile_enable(vet_ctx *ctx, int on);
 int vet_profile_reset(vet_ctx *ctx);
-/* kernel ids: 0 grid_dirs, 1 nearest_lut, 2 spatial_hist, 3 transition, 4 finalize */
+/* kernel ids: 0 k_grid_dirs, 1 k_nearest_lut, 2 k_spatial (any variant), 3 k_transition,
+ *             4 k_finalize, 5 k_wtab (direction weight table build) */
 int vet_profile_get(vet_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
 const char *vet_kernel_name(int kernel_id);
 
@@ -102,6 +103,14 @@ typedef struct vet_plan_desc {
 int vet_plan_create(vet_ctx *ctx, const vet_plan_desc *desc, vet_plan **out);
 int vet_plan_destroy(vet_plan *plan);
 int64_t vet_plan_n_dirs(const vet_plan *plan);
+/* Weighted spatial mode has two formulations with identical results up to the fixed-point
+ * resolution: (a) brute force, every sample sweeps every tile (FP64 VALU bound); (b) direction
+ * weight table, built once per plan and gathered per sample (memory bound).  policy: 0 auto
+ * (table when a call has at least as many samples as the plan has directions), 1 always table,
+ * -1 never.  vet_plan_table_stride: row length of lattice k's table, 0 = not built (yet),
+ * -1 = too large. */
+int vet_plan_set_table_policy(vet_plan *plan, int policy);
+int vet_plan_table_stride(const vet_plan *plan, int lattice);
 /* Parity hooks: read back the device-built tables (synchronous). */
 int vet_plan_read_dirs(vet_plan *plan, double *h_xyz /* [n_dirs*3] rounded Vector xyz */);
 int vet_plan_read_nearest(vet_plan *plan, int lattice, int32_t *h_nearest /* [n_dirs] */);

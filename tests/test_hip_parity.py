@@ -12,6 +12,14 @@ pytestmark = pytest.mark.gpu
 
 RTOL = 1e-9          # contract is 1e-6; the fixed-point histogram + FP64 entropy sits near 1e-13
 ATOL_W = 1e-12       # absolute tolerance on tile weight sums (fixed point resolution 2^-52 per add)
+# Weighted mode has two formulations (include/vet.h, vet_plan_set_table_policy): brute-force
+# sweep (-1) and direction weight table (+1, u32 fixed point: 2^-33 abs per weight).
+POLICIES = [pytest.param(-1, id="sweep"), pytest.param(1, id="table")]
+
+
+def tol(policy, users=1):
+    """(entropy rtol, weight-sum atol) per formulation."""
+    return (RTOL, ATOL_W) if policy < 0 else (1e-8, 2.0 ** -33 * users + ATOL_W)
 
 
 @pytest.fixture(scope="module")
@@ -25,9 +33,11 @@ def engine(native):
     return native.Engine.default()
 
 
-def make_plan(native, engine, tcs, W=100, H=200, fov=120.0, power=2.0, weighted=True, dir_table=None):
+def make_plan(native, engine, tcs, W=100, H=200, fov=120.0, power=2.0, weighted=True, dir_table=None, policy=0):
     tiles = [vo.fibonacci_lattice(tc) for tc in tcs]
-    return native.Plan(engine, tiles, fov, power, weighted, W, H, dir_table=dir_table)
+    plan = native.Plan(engine, tiles, fov, power, weighted, W, H, dir_table=dir_table)
+    plan.set_table_policy(policy)
+    return plan
 
 
 def load(golden_dir, name):
@@ -88,15 +98,19 @@ def _g4_dense(g, tag):
     ("w_tc50_fov90", [50], dict(fov=90.0)),
     ("w_tc100_fov200_p05", [100], dict(fov=200.0, power=0.5)),
 ])
-def test_spatial_vs_reference_goldens(native, engine, golden_dir, tag, tcs, kw):
+@pytest.mark.parametrize("policy", POLICIES)
+def test_spatial_vs_reference_goldens(native, engine, golden_dir, tag, tcs, kw, policy):
     g = load(golden_dir, "g4_spatial.npz")
     _, mu, mv = _g4_dense(g, tag)
-    plan = make_plan(native, engine, tcs, **kw)
+    plan = make_plan(native, engine, tcs, policy=policy, **kw)
     res = plan.spatial(mu=mu, mv=mv, want_assign=True, want_weights=True)
+    if kw.get("weighted", True):
+        assert (plan.table_stride(0) > 0) == (policy > 0)
+    rtol, atol = tol(policy, mu.shape[1])
     assert np.array_equal(res["assign"], g[f"{tag}__assign"])
-    np.testing.assert_allclose(res["entropy"], g[f"{tag}__entropy"], rtol=RTOL, equal_nan=True)
+    np.testing.assert_allclose(res["entropy"], g[f"{tag}__entropy"], rtol=rtol, equal_nan=True)
     fr = g[f"{tag}__weights_frames"]
-    np.testing.assert_allclose(res["weights"][fr], g[f"{tag}__weights"], rtol=1e-9, atol=ATOL_W)
+    np.testing.assert_allclose(res["weights"][fr], g[f"{tag}__weights"], rtol=1e-9, atol=atol)
     assert np.array_equal(res["present"], np.full(len(mu), mu.shape[1]))
     plan.close()
 
@@ -130,24 +144,24 @@ def test_dense_transition_bucket_quirk(native, engine, golden_dir, tc):
     assert np.array_equal(res["srccount"], g[f"tc{tc}__srccount"])
     np.testing.assert_allclose(res["entropy"], g[f"tc{tc}__entropy"], rtol=RTOL, equal_nan=True)
     plan.close()
-    for tag, weighted in (("u", False), ("w", True)):
-        plan = make_plan(native, engine, [tc], weighted=weighted)
+    for tag, weighted, policy in (("u", False, 0), ("w", True, -1), ("w", True, 1)):
+        plan = make_plan(native, engine, [tc], weighted=weighted, policy=policy)
         res = plan.spatial(mu=mu, mv=mv)
-        np.testing.assert_allclose(res["entropy"], g[f"tc{tc}__spatial_{tag}"], rtol=RTOL, equal_nan=True)
+        np.testing.assert_allclose(res["entropy"], g[f"tc{tc}__spatial_{tag}"], rtol=tol(policy)[0], equal_nan=True)
         assert np.array_equal(res["present"], present.sum(1))
         plan.close()
 
 
 def test_ingest_edge_cases(native, engine, golden_dir):
     g = load(golden_dir, "g6_ingest.npz")
-    for tag, weighted in (("w", True), ("u", False)):
+    for tag, weighted, policy in (("w", True, -1), ("w", True, 1), ("u", False, 0)):
         cols = [str(c) for c in g[f"{tag}__columns"]]
         tracks = [tuple(g[f"in_{c}"][:, i] for i in range(3)) for c in cols]
         _, mu, mv = vo.format_trajectories(tracks)
-        plan = make_plan(native, engine, [50, 20], weighted=weighted)
+        plan = make_plan(native, engine, [50, 20], weighted=weighted, policy=policy)
         res = plan.spatial(mu=mu, mv=mv)
         assert np.array_equal(res["assign"], g[f"{tag}__assign"])
-        np.testing.assert_allclose(res["entropy"], g[f"{tag}__entropy"], rtol=RTOL, equal_nan=True)
+        np.testing.assert_allclose(res["entropy"], g[f"{tag}__entropy"], rtol=tol(policy)[0], equal_nan=True)
         # transition on this data has rows without a common user -> VET_ERR_EMPTY
         tr = plan.transition(mu=mu, mv=mv, check=False)
         assert tr["code"] == native.VET_ERR_EMPTY
@@ -157,7 +171,8 @@ def test_ingest_edge_cases(native, engine, golden_dir):
         plan.close()
 
 
-def test_weight_rows_vs_reference(native, engine, golden_dir):
+@pytest.mark.parametrize("policy", POLICIES)
+def test_weight_rows_vs_reference(native, engine, golden_dir, policy):
     """One user per frame: the frame histogram is that direction's weight row."""
     g = load(golden_dir, "g7_weight_rows.npz")
     px, py = g["px"], g["py"]
@@ -167,10 +182,12 @@ def test_weight_rows_vs_reference(native, engine, golden_dir):
     mv[py == 200] = 1.0
     for tag, tc, kw in (("tc500", 500, {}), ("tc50_p15_fov90", 50, dict(power=1.5, fov=90.0)),
                         ("tc100_fov360", 100, dict(fov=360.0, power=3.0))):
-        plan = make_plan(native, engine, [tc], **kw)
+        plan = make_plan(native, engine, [tc], policy=policy, **kw)
         res = plan.spatial(mu=mu, mv=mv, want_weights=True)
         ref = g[f"{tag}__rows"]
-        np.testing.assert_allclose(res["weights"], ref, rtol=1e-9, atol=1e-15)
+        np.testing.assert_allclose(res["weights"], ref, rtol=1e-9, atol=1e-15 if policy < 0 else 2.0 ** -33)
+        if policy > 0:      # rows hold exactly the tiles the reference's dict holds
+            assert np.array_equal(res["weights"] > 0, ref >= 2.0 ** -33)
         assert np.array_equal(res["assign"][:, 0], g[f"{tag}__nearest"])
         plan.close()
 
@@ -193,19 +210,22 @@ def test_out_of_range_and_absent(native, engine):
     plan.close()
 
 
-@pytest.mark.parametrize("weighted", [True, False])
-def test_config2_vs_oracle(native, engine, weighted):
+@pytest.mark.parametrize("weighted,policy", [(True, -1), (True, 1), (True, 0), (False, 0)])
+def test_config2_vs_oracle(native, engine, weighted, policy):
     """BASELINE config 2: 64 users x 3000 frames, tile_counts=[50,100,200]."""
     from viewport_entropy_toolkit import _synthetic
     mu, mv = _synthetic.random_walk_video(64, 3000, base_seed=77, p_absent=0.05)
     tcs = [50, 100, 200]
-    plan = make_plan(native, engine, tcs, weighted=weighted)
+    plan = make_plan(native, engine, tcs, weighted=weighted, policy=policy)
     res = plan.spatial(mu=mu, mv=mv, want_weights=True)
+    if weighted and policy == 0:
+        assert plan.table_stride(0) > 0          # 192 000 samples >= 20 301 directions: auto = table
     ent, assign, weights = vo.spatial_series(mu, mv, 100, 200, tcs, use_weight_distribution=weighted,
                                              want_weights=True)
+    rtol, atol = tol(-1 if policy < 0 or not weighted else 1, 64)
     assert np.array_equal(res["assign"], assign)
-    np.testing.assert_allclose(res["entropy"], ent, rtol=RTOL, equal_nan=True)
-    np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=ATOL_W)
+    np.testing.assert_allclose(res["entropy"], ent, rtol=rtol, equal_nan=True)
+    np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=atol)
     plan.close()
 
 
@@ -221,7 +241,8 @@ def test_transition_random_vs_oracle(native, engine):
         plan.close()
 
 
-def test_explicit_direction_table_ids(native, engine):
+@pytest.mark.parametrize("policy", POLICIES)
+def test_explicit_direction_table_ids(native, engine, policy):
     """The *_ids entry points (operator boundary): arbitrary Vectors, not on the pixel grid."""
     rng = np.random.default_rng(9)
     lon, lat = rng.uniform(-180, 180, 300), rng.uniform(-90, 90, 300)
@@ -230,13 +251,14 @@ def test_explicit_direction_table_ids(native, engine):
     ids[rng.random(ids.shape) < 0.1] = -1
     ids[:, 0] = np.abs(ids[:, 0])
     L = vo.fibonacci_lattice(100)
-    plan = make_plan(native, engine, [100], dir_table=table)
+    plan = make_plan(native, engine, [100], dir_table=table, policy=policy)
     res = plan.spatial(ids=ids, want_weights=True)
+    rtol, atol = tol(policy, ids.shape[1])
     for t in range(len(ids)):
         d = table[ids[t][ids[t] >= 0]]
         e, hist, near = vo.spatial_entropy_frame(d, L)
-        np.testing.assert_allclose(res["entropy"][t], e, rtol=RTOL)
-        np.testing.assert_allclose(res["weights"][t], hist, rtol=1e-9, atol=ATOL_W)
+        np.testing.assert_allclose(res["entropy"][t], e, rtol=rtol)
+        np.testing.assert_allclose(res["weights"][t], hist, rtol=1e-9, atol=atol)
         assert np.array_equal(res["assign"][t][ids[t] >= 0], near)
     tr = plan.transition(ids=ids)
     near_all = vo.nearest_tile(table, L)
@@ -248,7 +270,8 @@ def test_explicit_direction_table_ids(native, engine):
 
 
 # --------------------------------------------------------------------------- full size, properties
-def test_config3_full_size_properties(native, engine):
+@pytest.mark.parametrize("policy", POLICIES)
+def test_config3_full_size_properties(native, engine, policy):
     """BASELINE config 3 (1024 users x 30000 frames, tile_counts=[500]): too big for the oracle
     as a whole, so: bit-reproducibility, invariance under user permutation and under splitting
     the frame axis (both exact thanks to the integer histogram), nearest == LUT, and a sample of
@@ -259,7 +282,7 @@ def test_config3_full_size_properties(native, engine):
     # cheap to generate: a random walk over frames for all users at once
     mu = np.mod(0.5 + np.cumsum(rng.normal(0, 0.01, (T, U)), axis=0), 1.0)
     mv = np.clip(0.5 + np.cumsum(rng.normal(0, 0.005, (T, U)), axis=0), 0.0, 1.0)
-    plan = make_plan(native, engine, [500])
+    plan = make_plan(native, engine, [500], policy=policy)
     a = plan.spatial(mu=mu, mv=mv, want_assign=True)
     b = plan.spatial(mu=mu, mv=mv, want_assign=False)
     assert np.array_equal(a["entropy"], b["entropy"])                    # run-to-run bit exact
@@ -275,8 +298,23 @@ def test_config3_full_size_properties(native, engine):
     frames = rng.integers(0, T, 12)
     ent, assign, _ = vo.spatial_series(mu[frames], mv[frames], 100, 200, [500])
     assert np.array_equal(a["assign"][frames], assign)
-    np.testing.assert_allclose(a["entropy"][frames], ent, rtol=RTOL)
+    np.testing.assert_allclose(a["entropy"][frames], ent, rtol=tol(policy)[0])
     plan.close()
+
+
+def test_sweep_and_table_formulations_agree(native, engine):
+    """Same video through both weighted formulations, three lattices, odd fov / power."""
+    from viewport_entropy_toolkit import _synthetic
+    mu, mv = _synthetic.random_walk_video(200, 500, base_seed=11, p_absent=0.02)
+    for kw in (dict(), dict(fov=90.0, power=1.0), dict(fov=200.0, power=0.7), dict(fov=360.0, power=3.0)):
+        out = []
+        for policy in (-1, 1):
+            plan = make_plan(native, engine, [20, 100, 250], policy=policy, **kw)
+            out.append(plan.spatial(mu=mu, mv=mv, want_weights=True))
+            plan.close()
+        assert np.array_equal(out[0]["assign"], out[1]["assign"])
+        np.testing.assert_allclose(out[1]["entropy"], out[0]["entropy"], rtol=1e-8)
+        np.testing.assert_allclose(out[1]["weights"], out[0]["weights"], rtol=0, atol=2.0 ** -33 * 200 + 1e-12)
 
 
 def test_config5_transition_full_size_properties(native, engine):

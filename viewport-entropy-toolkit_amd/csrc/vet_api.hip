@@ -37,9 +37,9 @@ int fail(int code, const char* fmt, ...) {
                         __FILE__, __LINE__);                                                 \
     } while (0)
 
-enum { KID_GRID = 0, KID_NEAREST = 1, KID_SPATIAL = 2, KID_TRANSITION = 3, KID_FINALIZE = 4, KID_COUNT = 5 };
+enum { KID_GRID = 0, KID_NEAREST = 1, KID_SPATIAL = 2, KID_TRANSITION = 3, KID_FINALIZE = 4, KID_WTAB = 5, KID_COUNT = 6 };
 const char* const kKernelNames[KID_COUNT] = {"k_grid_dirs", "k_nearest_lut", "k_spatial", "k_transition",
-                                             "k_finalize"};
+                                             "k_finalize", "k_wtab"};
 
 struct EventPair {
     int kid;
@@ -60,8 +60,8 @@ struct vet_ctx {
     bool profiling = false;
     std::vector<EventPair> pending;
     std::vector<hipEvent_t> free_events;
-    double prof_ms[KID_COUNT] = {0, 0, 0, 0, 0};
-    int64_t prof_n[KID_COUNT] = {0, 0, 0, 0, 0};
+    double prof_ms[KID_COUNT] = {0, 0, 0, 0, 0, 0};
+    int64_t prof_n[KID_COUNT] = {0, 0, 0, 0, 0, 0};
 };
 
 struct Lattice {
@@ -69,6 +69,11 @@ struct Lattice {
     double* d_tiles = nullptr;     // [n][3] unit
     uint16_t* d_nearest = nullptr; // [n_dirs]
     double hmax = 0.0;
+    // direction weight table (ELL), built on first use when the video has more samples than the
+    // plan has directions
+    uint32_t* d_tab_w = nullptr;   // [n_dirs][stride]
+    uint16_t* d_tab_i = nullptr;   // [n_dirs][stride]
+    int stride = 0;                // 0 = not built, -1 = not usable (too large)
 };
 
 struct vet_plan {
@@ -82,6 +87,7 @@ struct vet_plan {
     double fov = 120.0, max_ang = 0.0, power = 2.0;
     int weighted = 1;
     double cos_cull = 0.0;
+    int table_policy = 0;          // 0 auto, 1 always use the weight table, -1 never
 };
 
 namespace {
@@ -197,6 +203,53 @@ const void* spatial_w_kernel(int wmode, int R) {
     return nullptr;
 }
 
+constexpr size_t kMaxTableBytes = (size_t)24 << 30;   // per lattice; HBM is 288 GB
+
+// Builds lattice k's direction weight table on stream s (first use only; synchronises once).
+int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
+    Lattice& L = pl->lat[k];
+    if (L.stride != 0) return VET_OK;
+    vet_ctx* c = pl->ctx;
+    int* d_max = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_max, sizeof(int)));
+    HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(int), s));
+    vet::WtabParams p;
+    p.dir_unit = pl->d_dir_unit; p.D = (long)pl->n_dirs;
+    p.tiles = L.d_tiles; p.n = L.n;
+    p.cos_cull = pl->cos_cull;
+    p.wc.max_ang = pl->max_ang; p.wc.inv_max = 1.0 / pl->max_ang; p.wc.power = pl->power; p.wc.shift = 0;
+    p.stride = 0; p.w = nullptr; p.idx = nullptr; p.maxcount = d_max;
+    const int blocks = grid_for((long)pl->n_dirs * vet::WAVE, 256, c->n_cu * 2);
+    {
+        ProfScope ps(c, s, KID_WTAB);
+        hipLaunchKernelGGL(vet::k_wtab<false>, dim3(blocks), dim3(256), 0, s, p);
+    }
+    int longest = 0;
+    hipError_t e = hipMemcpyAsync(&longest, d_max, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_max);
+    if (e != hipSuccess) return fail(VET_ERR_DEVICE, "k_wtab<count> failed: %s", hipGetErrorString(e));
+    int stride = ((longest > 0 ? longest : 1) + 15) & ~15;
+    const size_t bytes = (size_t)pl->n_dirs * stride * 6;
+    if (bytes > kMaxTableBytes) { L.stride = -1; return VET_OK; }
+    HIP_TRY(hipMalloc((void**)&L.d_tab_w, (size_t)pl->n_dirs * stride * 4));
+    HIP_TRY(hipMalloc((void**)&L.d_tab_i, (size_t)pl->n_dirs * stride * 2));
+    p.stride = stride; p.w = L.d_tab_w; p.idx = L.d_tab_i; p.maxcount = nullptr;
+    {
+        ProfScope ps(c, s, KID_WTAB);
+        hipLaunchKernelGGL(vet::k_wtab<true>, dim3(blocks), dim3(256), 0, s, p);
+    }
+    HIP_TRY(hipGetLastError());
+    L.stride = stride;
+    return VET_OK;
+}
+
+bool want_table(const vet_plan* pl, int U, int T) {
+    if (!pl->weighted || pl->table_policy < 0) return false;
+    if (pl->table_policy > 0) return true;
+    return (long)U * T >= (long)pl->n_dirs;      // rows are reused on average at least once
+}
+
 template <bool FROM_IDS>
 int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double* d_entropy, int32_t* d_assign,
                    double* d_weights, int32_t* d_present, int32_t* d_status, hipStream_t s) {
@@ -234,6 +287,34 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         p.present = k == 0 ? d_present : nullptr;
         p.status = k == 0 ? d_status : nullptr;
         p.FPW = g.FPW; p.G = g.G; p.UC = g.UC;
+        if (want_table(pl, U, T)) {
+            rc = ensure_wtab(pl, k, s);
+            if (rc) return rc;
+        }
+        if (pl->weighted && pl->lat[k].stride > 0 && want_table(pl, U, T)) {
+            vet::LutParams q;
+            q.src = src; q.U = U; q.T = T;
+            q.nearest = L.d_nearest; q.tab_w = L.d_tab_w; q.tab_i = L.d_tab_i; q.stride = L.stride;
+            q.gs_log2 = L.stride >= 64 ? 6 : (L.stride > 16 ? 5 : 4);
+            q.n = L.n; q.hmax = L.hmax;
+            q.ent_k = p.ent_k; q.assign = p.assign; q.weights = p.weights; q.present = p.present; q.status = p.status;
+            // geometry: 8 waves; enough frames per workgroup to give every wave >= 8 users
+            q.UC = U < 2048 ? U : 2048;
+            int fpw = U >= 256 ? 1 : (U >= 64 ? 4 : 16);
+            size_t lds = 0;
+            for (;; fpw /= 2) {
+                lds = (size_t)fpw * L.n * 8 + (size_t)fpw * q.UC * 4 + (size_t)2 * fpw * 4 + 64;
+                if (lds <= c->lds_max || fpw == 1) break;
+            }
+            if (lds > c->lds_max)
+                return fail(VET_ERR_UNSUPPORTED, "lattice of %d tiles does not fit the LDS histogram (%zu B)", L.n, lds);
+            q.FPW = fpw;
+            const int blocks = (T + fpw - 1) / fpw;
+            ProfScope ps(c, s, KID_SPATIAL);
+            hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS>), dim3(blocks), dim3(U >= 512 ? 512 : 256), lds, s, q);
+            HIP_TRY(hipGetLastError());
+            continue;
+        }
         const int blocks = (T + g.FPW - 1) / g.FPW;
         const void* fn = pl->weighted ? spatial_w_kernel<FROM_IDS>(weight_mode(pl), g.R)
                                       : (const void*)vet::k_spatial_u<FROM_IDS>;
@@ -501,6 +582,8 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
             PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<false>(wm, R), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
             PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<true>(wm, R), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
         }
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
@@ -519,12 +602,25 @@ int vet_plan_destroy(vet_plan* pl) {
     for (auto& L : pl->lat) {
         if (L.d_tiles) (void)hipFree(L.d_tiles);
         if (L.d_nearest) (void)hipFree(L.d_nearest);
+        if (L.d_tab_w) (void)hipFree(L.d_tab_w);
+        if (L.d_tab_i) (void)hipFree(L.d_tab_i);
     }
     delete pl;
     return VET_OK;
 }
 
 int64_t vet_plan_n_dirs(const vet_plan* pl) { return pl ? pl->n_dirs : 0; }
+
+int vet_plan_set_table_policy(vet_plan* pl, int policy) {
+    if (!pl) return fail(VET_ERR_INVALID, "plan is NULL");
+    pl->table_policy = policy > 0 ? 1 : (policy < 0 ? -1 : 0);
+    return VET_OK;
+}
+
+int vet_plan_table_stride(const vet_plan* pl, int k) {
+    if (!pl || k < 0 || k >= (int)pl->lat.size()) return 0;
+    return pl->lat[k].stride;
+}
 
 int vet_plan_read_dirs(vet_plan* pl, double* h_xyz) {
     if (!pl || !h_xyz) return fail(VET_ERR_INVALID, "plan or output is NULL");

@@ -188,6 +188,45 @@ __device__ __forceinline__ unsigned long long fov_weight_fx(double c, const Weig
 }
 
 // ------------------------------------------------------------------------------------------
+// Entropy of the workgroup's frames from their fixed-point tile histograms
+// (entropy_utils.py:194-211, weighted mode: normaliser log2(n)).  Wave w takes frames w, w+NW, ...
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void weighted_frame_entropy(const unsigned long long* hist, const int* cnt_frame, int nf,
+                                                       long f0, int n, double fx_scale, double hmax,
+                                                       double* ent_k, double* weights, int32_t* present,
+                                                       int32_t* status) {
+    const int NW = blockDim.x >> 6, lane = lane_id(), wv = wave_id();
+    for (int fl = wv; fl < nf; fl += NW) {
+        const unsigned long long* hrow = hist + (size_t)fl * n;
+        // total weight: up to U*n/4 fixed-point units, which can exceed 64 bits, so it is summed
+        // in FP64 (fixed lane order + butterfly => still a pure function of the histogram)
+        double totd = 0.0;
+        for (int t = lane; t < n; t += WAVE) totd += (double)hrow[t];
+        totd = wave_sum(totd);
+        double h = 0.0;
+        for (int t = lane; t < n; t += WAVE) {
+            const unsigned long long v = hrow[t];
+            if (v) {
+                const double q = (double)v / totd;
+                h -= q * log2(q);
+            }
+            if (weights) weights[(f0 + fl) * (long)n + t] = (double)v / fx_scale;
+        }
+        h = wave_sum(h);
+        if (lane == 0) {
+            const int np = cnt_frame[fl];
+            double e = h / hmax;
+            if (np == 0) {
+                e = __builtin_nan("");
+                if (status) atomicAdd(&status[1], 1);
+            }
+            ent_k[f0 + fl] = e;
+            if (present) present[f0 + fl] = np;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_spatial_w — compute_spatial_entropy (entropy_utils.py:147-211), FoV-weighted mode, for FPW
 // frames per workgroup.
 //
@@ -318,36 +357,164 @@ __global__ void k_spatial_w(const SpatialParams p) {
     }
     __syncthreads();
 
-    // ---- entropy per frame (entropy_utils.py:194-211); wave wv takes frames wv, wv+NW, ...
-    const double fx_scale = (double)(1ull << (52 - p.wc.shift));
-    for (int fl = wv; fl < nf; fl += NW) {
-        const unsigned long long* hrow = hist + (size_t)fl * p.n;
-        // total weight: up to U*n/4 in units of 2^-s, which does not fit 64 bits, so it is summed
-        // in FP64 (fixed lane order + butterfly => still a pure function of the histogram)
-        double totd = 0.0;
-        for (int t = lane; t < p.n; t += WAVE) totd += (double)hrow[t];
-        totd = wave_sum(totd);
-        double h = 0.0;
-        for (int t = lane; t < p.n; t += WAVE) {
-            const unsigned long long v = hrow[t];
-            if (v) {
-                const double q = (double)v / totd;
-                h -= q * log2(q);
+    weighted_frame_entropy(hist, cnt_frame, nf, f0, p.n, (double)(1ull << (52 - p.wc.shift)), p.hmax, p.ent_k,
+                           p.weights, p.present, p.status);
+    if (p.status) {
+        const unsigned long long anybad = __ballot(bad);
+        if (anybad && lane == 0) atomicAdd(&p.status[0], (int)__popcll(anybad));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Direction weight table (ELL).  The sample domain is discrete — (W+1)(H+1) pixel directions —
+// and the weight of a (direction, tile) pair depends on nothing else, so for videos with more
+// samples than directions the rows  {(tile, w)} : w > 0  are evaluated once per plan (exact
+// ocml acos / pow, any fov and power) and the per-frame histogram becomes a gather of rows:
+//   hist[t] += w(dir(u), t)   for the ~n/4 tiles in the user's FoV.
+// Row d lives at w[d*stride .. ] (u32 fixed point, w * 2^32 rounded, saturating) and
+// idx[d*stride ..] (u16 tile), sorted by tile, zero padded.
+// k_wtab<false> finds the longest row (conservative cone test), k_wtab<true> fills the rows.
+// One wave per direction; lane = tile.
+// ------------------------------------------------------------------------------------------
+struct WtabParams {
+    const double* dir_unit;
+    long D;
+    const double* tiles;
+    int n;
+    double cos_cull;
+    WeightCfg wc;
+    int stride;
+    uint32_t* w;
+    uint16_t* idx;
+    int* maxcount;
+};
+
+template <bool FILL>
+__global__ void k_wtab(const WtabParams p) {
+    const int lane = lane_id();
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    int longest = 0;
+    for (long d = wave; d < p.D; d += nwaves) {
+        const double dx = p.dir_unit[3 * d], dy = p.dir_unit[3 * d + 1], dz = p.dir_unit[3 * d + 2];
+        int count = 0;
+        for (int t0 = 0; t0 < p.n; t0 += WAVE) {
+            const int t = t0 + lane;
+            const bool valid = t < p.n;
+            const int ts = valid ? t : 0;
+            const double c = fma(dz, p.tiles[3 * ts + 2], fma(dy, p.tiles[3 * ts + 1], dx * p.tiles[3 * ts]));
+            bool hit = valid && (c > p.cos_cull);
+            unsigned w32 = 0u;
+            if (FILL) {
+                if (hit) {
+                    const double cc = fmin(fmax(c, -1.0), 1.0);
+                    const double ang = acos(cc);
+                    double wt = 0.0;
+                    if (ang < p.wc.max_ang) wt = pow((p.wc.max_ang - ang) / p.wc.max_ang, p.wc.power);
+                    w32 = (unsigned)fmin(rint(wt * 4294967296.0), 4294967295.0);
+                }
+                hit = w32 != 0u;
             }
-            if (p.weights) p.weights[(f0 + fl) * (long)p.n + t] = (double)v / fx_scale;
+            const unsigned long long mask = __ballot(hit);
+            if (FILL && hit) {
+                const int pos = count + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                        __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                p.w[d * p.stride + pos] = w32;
+                p.idx[d * p.stride + pos] = (uint16_t)t;
+            }
+            count += __popcll(mask);
         }
-        h = wave_sum(h);
-        if (lane == 0) {
-            const int np = cnt_frame[fl];
-            double e = h / p.hmax;
-            if (np == 0) {
-                e = __builtin_nan("");
-                if (p.status) atomicAdd(&p.status[1], 1);
+        if (FILL) {
+            for (int pos = count + lane; pos < p.stride; pos += WAVE) {
+                p.w[d * p.stride + pos] = 0u;
+                p.idx[d * p.stride + pos] = 0;
             }
-            p.ent_k[f0 + fl] = e;
-            if (p.present) p.present[f0 + fl] = np;
+        }
+        longest = max(longest, count);
+    }
+    if (!FILL && lane == 0 && longest > 0) atomicMax(p.maxcount, longest);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_spatial_lut — compute_spatial_entropy (entropy_utils.py:147-211), FoV-weighted mode, through
+// the direction weight table.  FPW frames per workgroup.
+// LDS:  hist u64 [FPW][n]   per-frame tile weight sums (units of 2^-32)
+//       ids  i32 [FPW][UC]  direction ids of the present users (compacted)
+//       cnt  i32 [FPW] chunk-present, [FPW] frame-present
+// A group of GS = 2^gs_log2 lanes walks one user's row (coalesced u32 + u16 loads) and adds the
+// non-zero entries into the frame histogram with ds_add_u64; a wave serves 64/GS users at once
+// and two such steps are issued back to back to keep more loads in flight.
+// ------------------------------------------------------------------------------------------
+struct LutParams {
+    SampleSrc src;
+    int U, T;
+    const uint16_t* nearest;
+    const uint32_t* tab_w;
+    const uint16_t* tab_i;
+    int stride;
+    int gs_log2;
+    int n;
+    double hmax;
+    double* ent_k;
+    int32_t* assign;
+    double* weights;
+    int32_t* present;
+    int32_t* status;
+    int FPW, UC;
+};
+
+template <bool FROM_IDS>
+__global__ void k_spatial_lut(const LutParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NW = blockDim.x >> 6;
+    unsigned long long* hist = (unsigned long long*)smem;                        // [FPW][n]
+    int* ids = (int*)(hist + (size_t)p.FPW * p.n);                               // [FPW][UC]
+    int* cnt_chunk = ids + (size_t)p.FPW * p.UC;                                 // [FPW]
+    int* cnt_frame = cnt_chunk + p.FPW;                                          // [FPW]
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const long f0 = (long)blockIdx.x * p.FPW;
+    const int nf = (int)min((long)p.FPW, (long)p.T - f0);
+    for (int i = tid; i < p.FPW * p.n; i += blockDim.x) hist[i] = 0ull;
+    for (int i = tid; i < 2 * p.FPW; i += blockDim.x) cnt_chunk[i] = 0;
+    bool bad = false;
+    const int GS = 1 << p.gs_log2, UPW = WAVE >> p.gs_log2;
+    const int sub = lane >> p.gs_log2, sl = lane & (GS - 1);
+
+    for (int u0 = 0; u0 < p.U; u0 += p.UC) {
+        const int uc = min(p.UC, p.U - u0);
+        __syncthreads();
+        for (int i = tid; i < p.FPW; i += blockDim.x) cnt_chunk[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < nf * uc; i += blockDim.x) {
+            const int fl = i / uc, uu = i - fl * uc;
+            const long idx = (f0 + fl) * (long)p.U + u0 + uu;
+            const int id = sample_dir<FROM_IDS>(p.src, idx, bad);
+            if (id >= 0) ids[(size_t)fl * p.UC + atomicAdd(&cnt_chunk[fl], 1)] = id;
+            if (p.assign) p.assign[idx] = id >= 0 ? (int)p.nearest[id] : -1;
+        }
+        __syncthreads();
+        for (int i = tid; i < p.FPW; i += blockDim.x) cnt_frame[i] += cnt_chunk[i];
+        for (int fl = 0; fl < nf; ++fl) {
+            const int nu = cnt_chunk[fl];
+            const int* fids = ids + (size_t)fl * p.UC;
+            unsigned long long* hrow = hist + (size_t)fl * p.n;
+            const int step = NW * UPW;
+            for (int j0 = wv * UPW; j0 < nu; j0 += 2 * step) {
+                const int ja = j0 + sub, jb = j0 + step + sub;
+                const bool oa = ja < nu, ob = jb < nu;
+                const long ra = oa ? (long)fids[ja] * p.stride : 0, rb = ob ? (long)fids[jb] * p.stride : 0;
+                for (int e = sl; e < p.stride; e += GS) {
+                    const unsigned wa = oa ? p.tab_w[ra + e] : 0u, wb = ob ? p.tab_w[rb + e] : 0u;
+                    const unsigned ia = p.tab_i[ra + e], ib = p.tab_i[rb + e];
+                    if (wa) atomicAdd(&hrow[ia], (unsigned long long)wa);
+                    if (wb) atomicAdd(&hrow[ib], (unsigned long long)wb);
+                }
+            }
         }
     }
+    __syncthreads();
+    weighted_frame_entropy(hist, cnt_frame, nf, f0, p.n, 4294967296.0, p.hmax, p.ent_k, p.weights, p.present,
+                           p.status);
     if (p.status) {
         const unsigned long long anybad = __ballot(bad);
         if (anybad && lane == 0) atomicAdd(&p.status[0], (int)__popcll(anybad));

@@ -21,7 +21,8 @@ _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("VET_HIP_LIBRARY", _PKG_DIR.parent / "lib" / "libvet_hip.so"))
 
 VET_OK, VET_ERR_INVALID, VET_ERR_DEVICE, VET_ERR_RANGE, VET_ERR_EMPTY, VET_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
-KERNEL_IDS = {"k_grid_dirs": 0, "k_nearest_lut": 1, "k_spatial": 2, "k_transition": 3, "k_finalize": 4}
+KERNEL_IDS = {"k_grid_dirs": 0, "k_nearest_lut": 1, "k_spatial": 2, "k_transition": 3, "k_finalize": 4,
+              "k_wtab": 5}
 
 
 class NativeUnavailable(RuntimeError):
@@ -69,6 +70,8 @@ SIGNATURES = {
     "vet_plan_create": (_I, [_P, C.POINTER(_PlanDesc), C.POINTER(_P)]),
     "vet_plan_destroy": (_I, [_P]),
     "vet_plan_n_dirs": (_I64, [_P]),
+    "vet_plan_set_table_policy": (_I, [_P, _I]),
+    "vet_plan_table_stride": (_I, [_P, _I]),
     "vet_plan_read_dirs": (_I, [_P, _P]),
     "vet_plan_read_nearest": (_I, [_P, _I, _P]),
     "vet_spatial_entropy": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -211,6 +214,13 @@ class Plan:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+    def set_table_policy(self, policy: int):
+        """0 auto, 1 always use the direction weight table, -1 never (brute-force sweep)."""
+        _check(self.lib, self.lib.vet_plan_set_table_policy(self.handle, int(policy)))
+
+    def table_stride(self, lattice: int = 0) -> int:
+        return int(self.lib.vet_plan_table_stride(self.handle, lattice))
 
     # --- parity hooks ---------------------------------------------------------
     def read_dirs(self) -> np.ndarray:
