@@ -499,15 +499,26 @@ __global__ void k_spatial_lut(const LutParams p) {
             const int* fids = ids + (size_t)fl * p.UC;
             unsigned long long* hrow = hist + (size_t)fl * p.n;
             const int step = NW * UPW;
-            for (int j0 = wv * UPW; j0 < nu; j0 += 2 * step) {
-                const int ja = j0 + sub, jb = j0 + step + sub;
-                const bool oa = ja < nu, ob = jb < nu;
-                const long ra = oa ? (long)fids[ja] * p.stride : 0, rb = ob ? (long)fids[jb] * p.stride : 0;
+            constexpr int UN = 4;                       // users in flight per lane group
+            for (int j0 = wv * UPW; j0 < nu; j0 += UN * step) {
+                long row[UN];
+                bool on[UN];
+#pragma unroll
+                for (int k = 0; k < UN; ++k) {
+                    const int j = j0 + k * step + sub;
+                    on[k] = j < nu;
+                    row[k] = on[k] ? (long)fids[j] * p.stride : 0;
+                }
                 for (int e = sl; e < p.stride; e += GS) {
-                    const unsigned wa = oa ? p.tab_w[ra + e] : 0u, wb = ob ? p.tab_w[rb + e] : 0u;
-                    const unsigned ia = p.tab_i[ra + e], ib = p.tab_i[rb + e];
-                    if (wa) atomicAdd(&hrow[ia], (unsigned long long)wa);
-                    if (wb) atomicAdd(&hrow[ib], (unsigned long long)wb);
+                    unsigned w[UN], t[UN];
+#pragma unroll
+                    for (int k = 0; k < UN; ++k) {
+                        w[k] = p.tab_w[row[k] + e];
+                        t[k] = p.tab_i[row[k] + e];
+                    }
+#pragma unroll
+                    for (int k = 0; k < UN; ++k)
+                        if (on[k] && w[k]) atomicAdd(&hrow[t[k]], (unsigned long long)w[k]);
                 }
             }
         }
