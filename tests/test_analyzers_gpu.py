@@ -1,0 +1,168 @@
+"""GPU: the drop-in Python surface end to end (CSV directory -> run_analysis -> DataFrame / CSV /
+png) and the operator-level functions, against the reference's golden vectors."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import viewport_entropy_toolkit as vt
+from viewport_entropy_toolkit.config import AnalyzerConfig, EntropyConfig
+from viewport_entropy_toolkit.utilities import (calculate_tile_weights, compute_spatial_entropy,
+                                                compute_transition_entropy, find_nearest_tile,
+                                                generate_fibonacci_lattice)
+from oracle import vet_oracle as vo
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-8
+
+
+def _write_config1(golden_dir, d, npz="g4_spatial.npz"):
+    g = np.load(golden_dir / npz)
+    d.mkdir()
+    for u in range(len(g["mu_in"])):
+        pd.DataFrame({"time": g["time_in"][u], "2dmu": g["mu_in"][u], "2dmv": g["mv_in"][u], "x": 1}).to_csv(
+            d / f"user{u:03d}.csv", index=False)
+    return g
+
+
+@pytest.mark.parametrize("tag,tcs,ekw", [
+    ("w_tc50", [50], {}),
+    ("w_tc50_100_200", [50, 100, 200], {}),
+    ("u_tc20_50", [20, 50], dict(use_weight_distribution=False)),
+    ("w_tc50_fov90", [50], dict(fov_angle=90.0)),
+])
+def test_spatial_run_analysis(tmp_path, golden_dir, tag, tcs, ekw):
+    g = _write_config1(golden_dir, tmp_path / "video")
+    cfg = AnalyzerConfig(tile_counts=tcs, output_dir=tmp_path / "out", entropy_config=EntropyConfig(**ekw))
+    an = vt.SpatialEntropyAnalyzer(cfg)
+    an.run_analysis(tmp_path / "video", output_prefix="t")
+    res = an._entropy_results
+    assert list(res.columns) == ["time", "entropy", "tile_weights", "tile_assignments"]
+    assert np.array_equal(res["time"], g[f"{tag}__time"])
+    np.testing.assert_allclose(res["entropy"], g[f"{tag}__entropy"], rtol=RTOL)
+    cols = [str(c) for c in g[f"{tag}__columns"]]
+    tiles = an._fibonacci_vectors[tcs[0]]
+    for i in (0, 150, 299):
+        assert dict(res["tile_assignments"][i]) == {c: int(a) for c, a in zip(cols, g[f"{tag}__assign"][i])}
+    for k, i in enumerate(g[f"{tag}__weights_frames"]):
+        ref = {tiles[j]: w for j, w in enumerate(g[f"{tag}__weights"][k]) if w > 2.0 ** -33}
+        got = dict(res["tile_weights"][int(i)])
+        assert set(got) >= set(ref)
+        for key, w in ref.items():
+            assert got[key] == pytest.approx(w, rel=1e-8, abs=8 * 2.0 ** -33)
+    csvs = list((tmp_path / "out").glob("video_t_*.csv"))
+    pngs = list((tmp_path / "out").glob("video_t_*_graph.png"))
+    assert len(csvs) == 1 and len(pngs) == 1
+    out = pd.read_csv(csvs[0])
+    assert list(out.columns) == ["time", "entropy"] and len(out) == 300
+    np.testing.assert_allclose(out["entropy"], g[f"{tag}__entropy"], rtol=RTOL)
+
+
+@pytest.mark.parametrize("tag,tcs", [("tc200", [200]), ("tc20_50", [20, 50])])
+def test_transition_analyzer(tmp_path, golden_dir, tag, tcs):
+    g = _write_config1(golden_dir, tmp_path / "video", "g5_transition.npz")
+    cfg = AnalyzerConfig(tile_counts=tcs, output_dir=tmp_path / "out")
+    # (a) golden column order through the engine-native array ingest
+    cols = [str(c) for c in g[f"{tag}__columns"]]
+    order = [int(c[4:]) for c in cols]
+    times, mu, mv = vo.format_trajectories([(g["time_in"][u], g["mu_in"][u], g["mv_in"][u]) for u in order])
+    an = vt.TransitionEntropyAnalyzer(cfg)
+    an.load_arrays(times, mu, mv, cols)
+    res = an.compute_entropy()
+    assert len(res) == 299 and np.array_equal(res["time"], g[f"{tag}__time"])
+    np.testing.assert_allclose(res["entropy"], g[f"{tag}__entropy"], rtol=RTOL, equal_nan=True)
+    tiles = an._fibonacci_vectors[tcs[0]]
+    for i in (0, 100, 298):
+        assert dict(res["tile_assignments"][i]) == {c: tuple(int(x) for x in p) for c, p in zip(cols, g[f"{tag}__pairs"][i])}
+        assert dict(res["tile_weights"][i]) == {tiles[j]: int(n) for j, n in enumerate(g[f"{tag}__srccount"][i]) if n}
+    # (b) from the CSV directory: column order is this box's glob order, so compare with the
+    #     oracle run in that same order (the transition value depends on user order)
+    an2 = vt.TransitionEntropyAnalyzer(cfg)
+    an2.process_directory(tmp_path / "video")
+    res2 = an2.compute_entropy()
+    t2, mu2, mv2, names = an2._dense
+    ent, _ = vo.transition_series(mu2, mv2, 100, 200, tcs)
+    np.testing.assert_allclose(res2["entropy"], ent, rtol=RTOL, equal_nan=True)
+    an2.create_visualization("tr")
+    assert (tmp_path / "out" / "tr.csv").exists() and (tmp_path / "out" / "tr_graph.png").exists()
+
+
+def test_hand_assigned_vector_frame(tmp_path, golden_dir):
+    """A caller may replace ``_data_cache['vectors']`` with its own object frame (arbitrary
+    Vectors): the analyzer must honour it (ids path)."""
+    g = _write_config1(golden_dir, tmp_path / "video")
+    cfg = AnalyzerConfig(tile_counts=[50], output_dir=tmp_path / "out")
+    an = vt.SpatialEntropyAnalyzer(cfg)
+    an.process_directory(tmp_path / "video")
+    vec = an._data_cache["vectors"].iloc[:40].reset_index(drop=True)
+    an._data_cache["vectors"] = vec
+    res = an.compute_entropy()
+    assert len(res) == 40
+    names = [c for c in vec.columns if c != "time"]
+    L = vo.fibonacci_lattice(50)
+    for i in range(40):
+        d = np.array([[vec[c][i].x, vec[c][i].y, vec[c][i].z] for c in names if vec[c][i] is not None])
+        e, _, _ = vo.spatial_entropy_frame(d, L)
+        assert res["entropy"][i] == pytest.approx(e, rel=RTOL)
+
+
+def test_error_conventions(tmp_path, golden_dir):
+    g = np.load(golden_dir / "g6_ingest.npz")
+    d = tmp_path / "edge"
+    d.mkdir()
+    for c in ("ua", "ub", "uc"):
+        a = g[f"in_{c}"]
+        pd.DataFrame({"time": a[:, 0], "2dmu": a[:, 1], "2dmv": a[:, 2]}).to_csv(d / f"{c}.csv", index=False)
+    cfg = AnalyzerConfig(tile_counts=[50], output_dir=tmp_path / "out")
+    tr = vt.TransitionEntropyAnalyzer(cfg)
+    tr.process_directory(d)
+    with pytest.raises(ZeroDivisionError):            # reference: rows without a common user
+        tr.compute_entropy()
+    sp = vt.SpatialEntropyAnalyzer(cfg)
+    sp.process_directory(d)
+    assert len(sp.compute_entropy()) == len(g["w__time"])
+    sp.load_arrays(np.arange(2) * 0.1, np.array([[0.5, np.nan], [np.nan, np.nan]]), np.full((2, 2), 0.5))
+    with pytest.raises(vt.ValidationError):           # a frame without any user
+        sp.compute_entropy()
+
+
+def test_operator_level_functions(golden_dir):
+    g = np.load(golden_dir / "g9_operator_edges.npz")
+    L = generate_fibonacci_lattice(50)
+    v, v2 = vt.Vector(*g["v"]), vt.Vector(*g["v2"])
+    e, w, a = compute_spatial_entropy({"a": v}, L, EntropyConfig(use_weight_distribution=False))
+    assert np.isnan(e) and np.isnan(g["single_unweighted"]) and a == {"a": find_nearest_tile(v, L)}
+    e, w, a = compute_spatial_entropy({"a": v}, L, EntropyConfig())
+    assert e == pytest.approx(float(g["single_weighted"]), rel=RTOL)
+    e, w, a = compute_spatial_entropy({"a": v, "b": v2}, L, EntropyConfig(fov_angle=1.0))
+    assert e == 0.0 and w == {} and [a["a"], a["b"]] == g["tiny_fov_assign"].tolist()
+    e, _, _ = compute_spatial_entropy({"a": v, "b": v2}, generate_fibonacci_lattice(1), EntropyConfig())
+    assert np.isnan(e)
+    e, w, a = compute_transition_entropy({"a": v}, {"a": v2}, L, EntropyConfig(), 120)
+    assert np.isnan(e) and a == {"a": (find_nearest_tile(v, L), find_nearest_tile(v2, L))}
+    e, w, a = compute_transition_entropy({"a": v, "b": v2}, {"a": v2, "b": v}, L, EntropyConfig(), 120)
+    assert e == pytest.approx(float(g["trans_two"]), rel=RTOL)
+    assert sum(w.values()) == 2
+    with pytest.raises(vt.ValidationError):
+        compute_spatial_entropy({}, L, EntropyConfig())
+    with pytest.raises(vt.ValidationError):
+        compute_transition_entropy({}, {"a": v}, L, EntropyConfig(), 120)
+    with pytest.raises(ZeroDivisionError):
+        compute_transition_entropy({"a": v}, {"b": v}, L, EntropyConfig(), 120)
+
+
+def test_calculate_tile_weights_rows(golden_dir):
+    g = np.load(golden_dir / "g7_weight_rows.npz")
+    grid = vo.direction_grid(100, 200)
+    L = generate_fibonacci_lattice(500)
+    for i in (0, 1, 5, 17):
+        v = vt.Vector(*grid[g["py"][i], g["px"][i]])
+        ref = g["tc500__rows"][i]
+        got = calculate_tile_weights(v, L, EntropyConfig())
+        assert find_nearest_tile(v, L) == int(g["tc500__nearest"][i])
+        assert {L.index(t) for t in got} == set(np.nonzero(ref > 0)[0])
+        for t, w in got.items():
+            assert w == pytest.approx(ref[L.index(t)], rel=1e-9, abs=1e-15)
+        keys = list(got)
+        assert all(got[keys[k]] >= got[keys[k + 1]] for k in range(len(keys) - 1))   # ascending distance
+    assert calculate_tile_weights(v, L, EntropyConfig(use_weight_distribution=False)) == \
+        {L[find_nearest_tile(v, L)]: 1.0}

@@ -1,0 +1,208 @@
+"""Host-side logic of the drop-in package (no GPU): value types, configuration, quantiser
+tables, dense ingest and the object-frame materialisation, lazy result views."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import viewport_entropy_toolkit as vt
+from viewport_entropy_toolkit import _ingest, _quantiser, _results
+from viewport_entropy_toolkit.config import AnalyzerConfig, EntropyConfig, DEFAULT_OUTPUT_FORMATS
+from viewport_entropy_toolkit.utilities import (format_trajectory_data, generate_fibonacci_lattice,
+                                                normalize_to_pixel, pixel_to_spherical, process_viewport_data,
+                                                validate_video_dimensions)
+from oracle import vet_oracle as vo
+
+
+# ---- the reference's own constructor tests (tests/test_core.py), restated -------------------
+def test_value_types():
+    p = vt.Point(pixel_x=100, pixel_y=200)
+    assert (p.pixel_x, p.pixel_y) == (100, 200) and p.as_tuple() == (100, 200)
+    r = vt.RadialPoint(lon=45.0, lat=30.0)
+    assert (r.lon, r.lat) == (45.0, 30.0)
+    v = vt.Vector(x=1.0, y=2.0, z=3.0)
+    assert (v.x, v.y, v.z) == (1.0, 2.0, 3.0)
+    assert hash(vt.Vector(1.0, 0.0, 0.0)) == hash(vt.Vector(1.0, 0.0, 0.0))
+    with pytest.raises(vt.ValidationError):
+        vt.Point(-1, 0)
+    with pytest.raises(vt.ValidationError):
+        vt.RadialPoint(181.0, 0.0)
+    with pytest.raises(vt.ValidationError):
+        vt.Vector(0.0, 0.0, 0.0)
+    with pytest.raises(vt.ValidationError):
+        vt.Vector.from_spherical(0.0, 91.0)
+    assert issubclass(vt.ValidationError, vt.SpatialError)
+
+
+def test_analyzer_construction(tmp_path):
+    for cls in (vt.SpatialEntropyAnalyzer, vt.TransitionEntropyAnalyzer):
+        a = cls(config=AnalyzerConfig(video_width=100, video_height=200, output_dir=tmp_path / "o"))
+        assert a.config.video_width == 100 and a.config.video_height == 200
+        assert set(a._fibonacci_vectors) == set(vt.DEFAULT_TILE_COUNTS)
+        assert len(a._fibonacci_vectors[50]) == 51
+        with pytest.raises(vt.ValidationError):
+            a.compute_entropy()                      # no data yet
+        with pytest.raises(vt.ValidationError):
+            a.create_visualization("x")              # no results yet
+        with pytest.raises(FileNotFoundError):
+            a.process_directory(tmp_path / "missing")
+
+
+def test_config_validation(tmp_path):
+    cfg = AnalyzerConfig(output_dir=tmp_path / "made" / "deep")
+    assert (tmp_path / "made" / "deep").is_dir()
+    assert cfg.tile_counts == [20, 50, 100, 250, 1000] and (cfg.video_width, cfg.video_height) == (100, 200)
+    assert cfg.get_output_path("b", ".csv") == tmp_path / "made" / "deep" / "b.csv"
+    assert DEFAULT_OUTPUT_FORMATS == {"video": ".mp4", "data": ".csv", "plot": ".png"}
+    for bad in (dict(video_width=0), dict(tile_counts=[]), dict(tile_counts=[10, -1])):
+        with pytest.raises(ValueError):
+            AnalyzerConfig(output_dir=tmp_path, **bad)
+    e = EntropyConfig()
+    assert (e.fov_angle, e.use_weight_distribution, e.power_factor) == (120.0, True, 2.0)
+    for bad in (dict(fov_angle=0), dict(fov_angle=361), dict(power_factor=0)):
+        with pytest.raises(vt.ValidationError):
+            EntropyConfig(**bad)
+
+
+# ---- quantiser tables against the reference's golden vectors ---------------------------------
+def test_quantiser_tables_match_reference(golden_dir):
+    g = np.load(golden_dir / "g2_quantiser.npz")
+    for W, H in ((100, 200), (3840, 1920), (6, 4)):
+        lon, lat = _quantiser.axis_angles(W, H)
+        assert np.array_equal(lon, g[f"lon_{W}x{H}"]) and np.array_equal(lat, g[f"lat_{W}x{H}"])
+    lon, lat = _quantiser.axis_angles(100, 200)
+    assert np.array_equal(_quantiser.vector_xyz(lon[None, :], lat[:, None]), g["vec_100x200"])
+    # the axis tables the C-ABI receives reproduce the grid when combined as the device does
+    lc, ls, sp, cp = _quantiser.axis_trig(100, 200)
+    r6 = lambda v: np.rint(v * 1e6) / 1e6  # noqa: E731
+    grid = np.stack([r6(sp[:, None] * lc[None, :]), r6(sp[:, None] * ls[None, :]),
+                     np.broadcast_to(r6(cp)[:, None], (201, 101))], -1)
+    assert np.array_equal(grid, g["vec_100x200"])
+
+
+def test_lattice_matches_reference(golden_dir):
+    g = np.load(golden_dir / "g1_lattices.npz")
+    for key in g.files:
+        tc = int(key[2:])
+        L = generate_fibonacci_lattice(tc)
+        assert len(L) == 2 * (tc // 2) + 1
+        assert np.array_equal(np.array([[v.x, v.y, v.z] for v in L]), g[key])
+    with pytest.raises(vt.ValidationError):
+        generate_fibonacci_lattice(0)
+    assert _quantiser.max_entropy(51) == pytest.approx(np.log2(51))
+
+
+# ---- ingest -----------------------------------------------------------------------------------
+def test_pixel_helpers():
+    assert normalize_to_pixel(np.array([0.0, 0.999, 1.0, 0.5]), 100).tolist() == [0, 99, 100, 50]
+    with pytest.raises(vt.ValidationError):
+        normalize_to_pixel(np.array([1.01]), 100)
+    with pytest.raises(vt.ValidationError):
+        validate_video_dimensions(101, 200)
+    rp = pixel_to_spherical(vt.Point(100, 200), 100, 200)
+    assert (rp.lon, rp.lat) == (180.0, -90.0)
+    with pytest.raises(vt.ValidationError):
+        pixel_to_spherical(vt.Point(101, 0), 100, 200)
+
+
+def _edge_tracks(golden_dir, tag="w"):
+    g = np.load(golden_dir / "g6_ingest.npz")
+    cols = [str(c) for c in g[f"{tag}__columns"]]
+    return g, cols, [tuple(g[f"in_{c}"][:, i] for i in range(3)) for c in cols]
+
+
+def _clean(t, a, b):
+    keep = ~(np.isnan(t) | np.isnan(a) | np.isnan(b))
+    t, a, b = t[keep], a[keep], b[keep]
+    return t - t.min(), a, b
+
+
+def test_dense_ingest_matches_reference_edges(golden_dir):
+    g, cols, tracks = _edge_tracks(golden_dir)
+    times, mu, mv = _ingest.build_dense([_clean(*tr) for tr in tracks])
+    assert np.array_equal(times, g["w__time"])                       # first-appearance order, not sorted
+    t2, mu2, mv2 = vo.format_trajectories(tracks)
+    assert np.array_equal(times, t2)
+    assert np.array_equal(mu, mu2, equal_nan=True) and np.array_equal(mv, mv2, equal_nan=True)
+    present = ~np.isnan(g["w__lonlat"][..., 0])
+    assert np.array_equal(~np.isnan(mu), present)
+
+
+def test_dense_ingest_random_tracks_vs_oracle():
+    rng = np.random.default_rng(8)
+    tracks = []
+    for u in range(7):
+        n = int(rng.integers(5, 60))
+        t = np.round(rng.uniform(0, 6, n), 2) + 100.0            # unsorted, with duplicates after rounding
+        tracks.append((t, rng.random(n), rng.random(n)))
+    a = _ingest.build_dense([_clean(*tr) for tr in tracks])
+    b = vo.format_trajectories(tracks)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_csv_ingest_and_object_frames(tmp_path, golden_dir):
+    g, cols, tracks = _edge_tracks(golden_dir)
+    d = tmp_path / "edge"
+    d.mkdir()
+    for c, (t, a, b) in zip(cols, tracks):
+        pd.DataFrame({"time": t, "2dmu": a, "2dmv": b, "other": 0}).to_csv(d / f"{c}.csv", index=False)
+    traj = []
+    for c in cols:
+        df, ident = process_viewport_data(d / f"{c}.csv", 100, 200)
+        assert ident == c and list(df.columns) == ["time", "2dmu", "2dmv", "pixel_x", "pixel_y", "lon", "lat"]
+        assert df["time"].min() == 0.0
+        traj.append((ident, df))
+    points, vectors = format_trajectory_data(traj)
+    assert list(points.columns) == ["time"] + cols and np.array_equal(points["time"], g["w__time"])
+    for j, c in enumerate(cols):
+        for i in range(len(points)):
+            rp, v = points[c][i], vectors[c][i]
+            if np.isnan(g["w__lonlat"][i, j, 0]):
+                assert rp is None and v is None
+            else:
+                assert (rp.lon, rp.lat) == tuple(g["w__lonlat"][i, j])
+                assert (v.x, v.y, v.z) == tuple(g["w__xyz"][i, j])
+    # failures are funnelled into ValidationError like the reference
+    with pytest.raises(vt.ValidationError):
+        process_viewport_data(d / "nope.csv", 100, 200)
+    pd.DataFrame({"time": [0.0], "2dmu": [1.5], "2dmv": [0.5]}).to_csv(d / "bad.csv", index=False)
+    with pytest.raises(vt.ValidationError):
+        process_viewport_data(d / "bad.csv", 100, 200)
+    with pytest.raises(vt.ValidationError):
+        format_trajectory_data([])
+
+
+def test_process_directory_builds_dense_arrays(tmp_path, golden_dir):
+    g, cols, tracks = _edge_tracks(golden_dir)
+    d = tmp_path / "video"
+    d.mkdir()
+    for c, (t, a, b) in zip(cols, tracks):
+        pd.DataFrame({"time": t, "2dmu": a, "2dmv": b}).to_csv(d / f"{c}.csv", index=False)
+    an = vt.SpatialEntropyAnalyzer(AnalyzerConfig(output_dir=tmp_path / "o", tile_counts=[50]))
+    an.process_directory(d)
+    times, mu, mv, names = an._dense
+    order = [cols.index(n) for n in names]                           # glob order is filesystem order
+    t2, mu2, mv2 = vo.format_trajectories([tracks[i] for i in order])
+    assert np.array_equal(times, t2) and np.array_equal(mu, mu2, equal_nan=True)
+    assert set(an._data_cache.keys()) >= {"points", "vectors", "trajectory_data"}
+    vec = an._data_cache["vectors"]                                   # lazily materialised object frame
+    assert list(vec.columns) == ["time"] + names and len(vec) == len(times)
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    pd.DataFrame({"time": [0.0], "2dmu": [2.0], "2dmv": [0.5]}).to_csv(bad / "u.csv", index=False)
+    with pytest.raises(vt.ValidationError, match="Failed to process directory"):
+        an.process_directory(bad)
+
+
+# ---- lazy result views ---------------------------------------------------------------------------
+def test_result_views_behave_like_the_reference_dicts():
+    tiles = generate_fibonacci_lattice(4)
+    tw = _results.TileWeights(tiles, np.array([0.0, 0.5, 0.0, 1.25, 0.0]))
+    assert dict(tw) == {tiles[1]: 0.5, tiles[3]: 1.25} and len(tw) == 2 and tw[tiles[3]] == 1.25
+    assert tw == {tiles[1]: 0.5, tiles[3]: 1.25}
+    ta = _results.TileAssignments(["a", "b", "c"], np.array([3, -1, 0]))
+    assert dict(ta) == {"a": 3, "c": 0} and "b" not in ta
+    tp = _results.TilePairs(["a", "b"], np.array([[1, 2], [-1, -1]]))
+    assert dict(tp) == {"a": (1, 2)}
+    cnt = _results.TileWeights(tiles, np.array([0, 2, 0, 0, 1]), as_int=True)
+    assert dict(cnt) == {tiles[1]: 2, tiles[4]: 1} and all(isinstance(v, int) for v in cnt.values())

@@ -1,0 +1,116 @@
+"""Multi-GPU scale-out: one process per GPU, videos (or frame blocks) sharded across ranks,
+one gather of the entropy time-series.
+
+The reference has no distributed code; its README suggests one process per video
+(README.md:108-120).  The path shards naturally:
+
+* videos are independent              -> rank r takes videos r, r+W, r+2W, ...
+* spatial frames are independent, and a transition row needs only the previous frame
+                                        -> contiguous frame blocks with a 1-frame halo
+* the only exchange is the result: ONE gather of the per-rank series to rank 0
+  (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU).
+
+No collective touches the data path.  ``compute`` callbacks receive numpy arrays and return the
+per-frame series; the analyzers' engine call is the default in bench.py, tests pass the oracle.
+"""
+
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def video_shard(n_videos: int, rank: int, world: int) -> List[int]:
+    """Round-robin video indices of ``rank``."""
+    if world <= 0 or not 0 <= rank < world:
+        raise ValueError("need 0 <= rank < world")
+    return list(range(rank, n_videos, world))
+
+
+def frame_shard(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [start, stop) of output rows for ``rank`` (sizes differ by at most 1)."""
+    if world <= 0 or not 0 <= rank < world:
+        raise ValueError("need 0 <= rank < world")
+    base, extra = divmod(n_rows, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def transition_frame_block(n_frames: int, rank: int, world: int) -> Tuple[int, int, int, int]:
+    """Transition rows [r0, r1) of ``rank`` and the frames [f0, f1) they need (1-frame halo:
+    row r compares frames r and r+1)."""
+    r0, r1 = frame_shard(max(n_frames - 1, 0), rank, world)
+    return r0, r1, r0, (r1 + 1 if r1 > r0 else r0)
+
+
+def gather_series(series: np.ndarray, dst: int = 0, max_len: Optional[int] = None, device=None):
+    """ONE gather of every rank's 1-D float64 series to ``dst``.
+
+    The payload is ``[len, values..., padding]`` of a common size; ``max_len`` (known when all
+    videos have the same number of frames) avoids the extra MAX all-reduce.  Returns the list
+    of per-rank arrays on ``dst`` and ``None`` elsewhere.  Works without an initialised
+    process group (single process)."""
+    import torch
+    import torch.distributed as dist
+
+    series = np.ascontiguousarray(series, dtype=np.float64).reshape(-1)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [series.copy()]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = device if device is not None else torch.device("cpu")
+    if max_len is None:
+        m = torch.tensor([len(series)], dtype=torch.int64, device=dev)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        max_len = int(m.item())
+    if len(series) > max_len:
+        raise ValueError("series longer than max_len")
+    payload = torch.zeros(max_len + 1, dtype=torch.float64, device=dev)
+    payload[0] = float(len(series))
+    payload[1:1 + len(series)] = torch.from_numpy(series).to(dev)
+    out = [torch.empty_like(payload) for _ in range(world)] if rank == dst else None
+    dist.gather(payload, out, dst=dst)
+    if rank != dst:
+        return None
+    res = []
+    for t in out:
+        t = t.cpu().numpy()
+        res.append(t[1:1 + int(t[0])].copy())
+    return res
+
+
+def analyze_videos(videos: Sequence, compute: Callable[[object], np.ndarray], dst: int = 0,
+                   max_len: Optional[int] = None, device=None):
+    """One video per rank at a time: rank r computes videos r, r+W, ...; after each round ONE
+    gather brings that round's series to ``dst``.  Returns {video index: series} on ``dst``."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    results = {}
+    rounds = (len(videos) + world - 1) // world
+    for rd in range(rounds):
+        vid = rd * world + rank
+        series = compute(videos[vid]) if vid < len(videos) else np.empty(0)
+        got = gather_series(series, dst=dst, max_len=max_len, device=device)
+        if got is not None:
+            for r, s in enumerate(got):
+                if rd * world + r < len(videos):
+                    results[rd * world + r] = s
+    return results if rank == dst else None
+
+
+def transition_frame_sharded(mu: np.ndarray, mv: np.ndarray, compute: Callable[[np.ndarray, np.ndarray], np.ndarray],
+                             dst: int = 0, device=None):
+    """One video across all ranks in transition mode: each rank computes a contiguous block of
+    rows from its frames plus a 1-frame halo; ONE gather concatenates them on ``dst``."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    T = mu.shape[0]
+    r0, r1, f0, f1 = transition_frame_block(T, rank, world)
+    part = compute(mu[f0:f1], mv[f0:f1]) if r1 > r0 else np.empty(0)
+    base, extra = divmod(max(T - 1, 0), world)
+    got = gather_series(part, dst=dst, max_len=base + (1 if extra else 0), device=device)
+    return np.concatenate(got) if got is not None else None

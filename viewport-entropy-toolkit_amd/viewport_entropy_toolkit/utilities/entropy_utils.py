@@ -37,8 +37,10 @@ def _xyz(vectors) -> np.ndarray:
 
 
 def _plan_for(vectors: List[Vector], tile_centers: List[Vector], config: EntropyConfig) -> "_native.Plan":
-    return _native.Plan(_native.Engine.default(), [_xyz(tile_centers)], config.fov_angle, config.power_factor,
+    plan = _native.Plan(_native.Engine.default(), [_xyz(tile_centers)], config.fov_angle, config.power_factor,
                         config.use_weight_distribution, dir_table=_xyz(vectors))
+    plan.set_table_policy(-1)        # a handful of samples: sweep directly, full 2^-52 weight resolution
+    return plan
 
 
 def find_nearest_tile(vector: Vector, tile_centers: List[Vector]) -> int:
