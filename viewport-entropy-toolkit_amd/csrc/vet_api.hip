@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -73,6 +74,7 @@ struct Lattice {
     // plan has directions
     uint32_t* d_tab_w = nullptr;   // [n_dirs][stride]
     uint16_t* d_tab_i = nullptr;   // [n_dirs][stride]
+    uint16_t* d_tab_len = nullptr; // [n_dirs]
     int stride = 0;                // 0 = not built, -1 = not usable (too large)
 };
 
@@ -218,7 +220,7 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     p.tiles = L.d_tiles; p.n = L.n;
     p.cos_cull = pl->cos_cull;
     p.wc.max_ang = pl->max_ang; p.wc.inv_max = 1.0 / pl->max_ang; p.wc.power = pl->power; p.wc.shift = 0;
-    p.stride = 0; p.w = nullptr; p.idx = nullptr; p.maxcount = d_max;
+    p.stride = 0; p.w = nullptr; p.idx = nullptr; p.len = nullptr; p.maxcount = d_max;
     const int blocks = grid_for((long)pl->n_dirs * vet::WAVE, 256, c->n_cu * 2);
     {
         ProfScope ps(c, s, KID_WTAB);
@@ -234,7 +236,8 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     if (bytes > kMaxTableBytes) { L.stride = -1; return VET_OK; }
     HIP_TRY(hipMalloc((void**)&L.d_tab_w, (size_t)pl->n_dirs * stride * 4));
     HIP_TRY(hipMalloc((void**)&L.d_tab_i, (size_t)pl->n_dirs * stride * 2));
-    p.stride = stride; p.w = L.d_tab_w; p.idx = L.d_tab_i; p.maxcount = nullptr;
+    HIP_TRY(hipMalloc((void**)&L.d_tab_len, (size_t)pl->n_dirs * 2));
+    p.stride = stride; p.w = L.d_tab_w; p.idx = L.d_tab_i; p.len = L.d_tab_len; p.maxcount = nullptr;
     {
         ProfScope ps(c, s, KID_WTAB);
         hipLaunchKernelGGL(vet::k_wtab<true>, dim3(blocks), dim3(256), 0, s, p);
@@ -294,8 +297,12 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         if (pl->weighted && pl->lat[k].stride > 0 && want_table(pl, U, T)) {
             vet::LutParams q;
             q.src = src; q.U = U; q.T = T;
-            q.nearest = L.d_nearest; q.tab_w = L.d_tab_w; q.tab_i = L.d_tab_i; q.stride = L.stride;
-            q.gs_log2 = L.stride >= 64 ? 6 : (L.stride > 16 ? 5 : 4);
+            q.nearest = L.d_nearest; q.tab_w = L.d_tab_w; q.tab_i = L.d_tab_i; q.tab_len = L.d_tab_len; q.stride = L.stride;
+            // lane group per row: 32 lanes unless the rows are tiny (measured: profiles/r01 sweep)
+            q.gs_log2 = L.stride > 16 ? 5 : 4;
+            if (const char* e = getenv("VET_GS_LOG2")) q.gs_log2 = atoi(e);
+            int un = 8;
+            if (const char* e = getenv("VET_UN")) un = atoi(e);
             q.n = L.n; q.hmax = L.hmax;
             q.ent_k = p.ent_k; q.assign = p.assign; q.weights = p.weights; q.present = p.present; q.status = p.status;
             // geometry: 8 waves; enough frames per workgroup to give every wave >= 8 users
@@ -311,7 +318,11 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
             q.FPW = fpw;
             const int blocks = (T + fpw - 1) / fpw;
             ProfScope ps(c, s, KID_SPATIAL);
-            hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS>), dim3(blocks), dim3(U >= 512 ? 512 : 256), lds, s, q);
+            int threads = 256;
+            if (const char* e = getenv("VET_LUT_THREADS")) threads = atoi(e);
+            if (un == 8) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 8>), dim3(blocks), dim3(threads), lds, s, q);
+            else if (un == 2) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2>), dim3(blocks), dim3(threads), lds, s, q);
+            else hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 4>), dim3(blocks), dim3(threads), lds, s, q);
             HIP_TRY(hipGetLastError());
             continue;
         }
@@ -582,8 +593,8 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
             PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<false>(wm, R), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
             PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<true>(wm, R), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
         }
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
@@ -604,6 +615,7 @@ int vet_plan_destroy(vet_plan* pl) {
         if (L.d_nearest) (void)hipFree(L.d_nearest);
         if (L.d_tab_w) (void)hipFree(L.d_tab_w);
         if (L.d_tab_i) (void)hipFree(L.d_tab_i);
+        if (L.d_tab_len) (void)hipFree(L.d_tab_len);
     }
     delete pl;
     return VET_OK;

@@ -386,6 +386,7 @@ struct WtabParams {
     int stride;
     uint32_t* w;
     uint16_t* idx;
+    uint16_t* len;      // [D] entries in use per row
     int* maxcount;
 };
 
@@ -429,6 +430,7 @@ __global__ void k_wtab(const WtabParams p) {
                 p.w[d * p.stride + pos] = 0u;
                 p.idx[d * p.stride + pos] = 0;
             }
+            if (lane == 0) p.len[d] = (uint16_t)count;
         }
         longest = max(longest, count);
     }
@@ -451,6 +453,7 @@ struct LutParams {
     const uint16_t* nearest;
     const uint32_t* tab_w;
     const uint16_t* tab_i;
+    const uint16_t* tab_len;
     int stride;
     int gs_log2;
     int n;
@@ -463,7 +466,7 @@ struct LutParams {
     int FPW, UC;
 };
 
-template <bool FROM_IDS>
+template <bool FROM_IDS, int UN>
 __global__ void k_spatial_lut(const LutParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NW = blockDim.x >> 6;
@@ -499,17 +502,19 @@ __global__ void k_spatial_lut(const LutParams p) {
             const int* fids = ids + (size_t)fl * p.UC;
             unsigned long long* hrow = hist + (size_t)fl * p.n;
             const int step = NW * UPW;
-            constexpr int UN = 4;                       // users in flight per lane group
             for (int j0 = wv * UPW; j0 < nu; j0 += UN * step) {
                 long row[UN];
                 bool on[UN];
+                int longest = 0;                        // rows are zero padded: walk to the longest only
 #pragma unroll
                 for (int k = 0; k < UN; ++k) {
                     const int j = j0 + k * step + sub;
                     on[k] = j < nu;
-                    row[k] = on[k] ? (long)fids[j] * p.stride : 0;
+                    const int id = on[k] ? fids[j] : 0;
+                    row[k] = (long)id * p.stride;
+                    longest = max(longest, on[k] ? (int)p.tab_len[id] : 0);
                 }
-                for (int e = sl; e < p.stride; e += GS) {
+                for (int e = sl; e < longest; e += GS) {
                     unsigned w[UN], t[UN];
 #pragma unroll
                     for (int k = 0; k < UN; ++k) {
