@@ -57,6 +57,7 @@ struct vet_ctx {
     // grow-only workspace for per-lattice entropies + status words of the host variants
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    double* d_log2 = nullptr;      // log2(k), k = 0..4096
     // profiling
     bool profiling = false;
     std::vector<EventPair> pending;
@@ -162,7 +163,9 @@ int spatial_geometry(const vet_ctx* c, int n, int U, bool weighted, Geometry* g)
         // k_spatial_u: one wave per frame in the entropy phase; keep >= 2048 samples per workgroup
         g->R = 1; g->G = 1; g->UC = 0;
         g->NW = 4;
-        g->FPW = U >= 1024 ? 2 : (U >= 256 ? 4 : 16);
+        if (const char* e = getenv("VET_U_WAVES")) g->NW = atoi(e);
+        g->FPW = U >= 2048 ? 2 : (U >= 512 ? 4 : (U >= 128 ? 8 : 32));
+        if (const char* e = getenv("VET_U_FPW")) g->FPW = atoi(e);
         while ((size_t)g->FPW * n * 4 > c->lds_max && g->FPW > 1) g->FPW /= 2;
         g->lds = (size_t)g->FPW * n * 4;
         if (g->lds > c->lds_max)
@@ -290,6 +293,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         p.present = k == 0 ? d_present : nullptr;
         p.status = k == 0 ? d_status : nullptr;
         p.FPW = g.FPW; p.G = g.G; p.UC = g.UC;
+        p.log2_tab = c->d_log2;
         if (want_table(pl, U, T)) {
             rc = ensure_wtab(pl, k, s);
             if (rc) return rc;
@@ -325,6 +329,26 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
             else hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 4>), dim3(blocks), dim3(threads), lds, s, q);
             HIP_TRY(hipGetLastError());
             continue;
+        }
+        if (!pl->weighted && !FROM_IDS && (U & 1) == 0 && U <= 4096 && !p.weights && !getenv("VET_U_NO_LDS")) {
+            // persistent variant with the nearest LUT in LDS: FB frames x U/2 pairs <= 2048 per round
+            constexpr int THREADS = 1024;
+            int FB = 2048 / (U / 2);
+            if (FB > 64) FB = 64;
+            const size_t lds = (((size_t)pl->n_dirs * 2 + 15) & ~(size_t)15) + (size_t)(U + 1) * 8 +
+                               ((((size_t)FB * L.n + 1) & ~(size_t)1) * 4) + (size_t)FB * (THREADS / 64) * 8 + FB * 4 + 16;
+            if (lds <= c->lds_max) {
+                vet::SpatialParams q = p;
+                q.FPW = FB;
+                const long nblk = ((long)T + FB - 1) / FB;
+                long grid = (long)c->n_cu * 2;
+                if (const char* e = getenv("VET_U_WGS_PER_CU")) grid = (long)c->n_cu * atoi(e);
+                if (grid > nblk) grid = nblk;
+                ProfScope ps(c, s, KID_SPATIAL);
+                hipLaunchKernelGGL(vet::k_spatial_u_lds, dim3((unsigned)grid), dim3(THREADS), lds, s, q);
+                HIP_TRY(hipGetLastError());
+                continue;
+            }
         }
         const int blocks = (T + g.FPW - 1) / g.FPW;
         const void* fn = pl->weighted ? spatial_w_kernel<FROM_IDS>(weight_mode(pl), g.R)
@@ -428,6 +452,9 @@ int vet_create(int device_id, vet_ctx** out) {
     // keep two workgroups per CU resident: cap a workgroup at half of the 160 KiB LDS
     c->lds_max = prop.sharedMemPerBlock >= 160 * 1024 ? 80 * 1024 : (size_t)prop.sharedMemPerBlock;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void**)&c->d_log2, 4097 * sizeof(double)));
+    hipLaunchKernelGGL(vet::k_log2_table, dim3(17), dim3(256), 0, c->stream, c->d_log2, 4097);
+    HIP_TRY(hipStreamSynchronize(c->stream));
     *out = c;
     return VET_OK;
 }
@@ -439,6 +466,7 @@ int vet_destroy(vet_ctx* c) {
     for (auto& ep : c->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     if (c->ws) (void)hipFree(c->ws);
+    if (c->d_log2) (void)hipFree(c->d_log2);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return VET_OK;
@@ -595,6 +623,7 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
         }
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));

@@ -25,6 +25,14 @@ constexpr unsigned EMPTY_KEY = 0xFFFFFFFFu;
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would
+// serialise a register prefetch issued just before it.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
@@ -110,8 +118,15 @@ struct SampleSrc {
     long n_dirs;
 };
 
-// returns direction id, -1 when absent; sets bad when a value is outside [0,1]
+// (mu, mv) -> direction id on the pixel grid, -1 when absent; sets bad when outside [0,1]
 // (normalize_to_pixel, data_utils.py:243-261: (v * dim).astype(int) truncates toward zero)
+__device__ __forceinline__ int grid_dir(double m, double v, int W, int H, bool& bad) {
+    if (m != m || v != v) return -1;                           // dropna()
+    if (!(m >= 0.0 && m <= 1.0 && v >= 0.0 && v <= 1.0)) { bad = true; return -1; }
+    return (int)(v * (double)H) * (W + 1) + (int)(m * (double)W);
+}
+
+// returns direction id, -1 when absent; sets bad when a value is outside [0,1]
 template <bool FROM_IDS>
 __device__ __forceinline__ int sample_dir(const SampleSrc& s, long idx, bool& bad) {
     if (FROM_IDS) {
@@ -119,12 +134,7 @@ __device__ __forceinline__ int sample_dir(const SampleSrc& s, long idx, bool& ba
         if (id >= s.n_dirs) { bad = true; return -1; }
         return id < 0 ? -1 : id;
     } else {
-        const double m = s.mu[idx], v = s.mv[idx];
-        if (m != m || v != v) return -1;                       // dropna()
-        if (!(m >= 0.0 && m <= 1.0 && v >= 0.0 && v <= 1.0)) { bad = true; return -1; }
-        const int px = (int)(m * (double)s.W);
-        const int py = (int)(v * (double)s.H);
-        return py * (s.W + 1) + px;
+        return grid_dir(s.mu[idx], s.mv[idx], s.W, s.H, bad);
     }
 }
 
@@ -260,6 +270,7 @@ struct SpatialParams {
     int FPW;                      // frames per workgroup
     int G;                        // tile groups per frame = ceil(n / (64*R))
     int UC;                       // users per LDS chunk
+    const double* log2_tab;       // [4097] log2(k), k = 0..4096 (entry 0 is 0); k_spatial_u_lds only
 };
 
 template <bool FROM_IDS, int WMODE, int R>
@@ -554,16 +565,66 @@ __global__ void k_spatial_u(const SpatialParams p) {
     for (int i = tid; i < p.FPW * p.n; i += blockDim.x) cnt[i] = 0u;
     __syncthreads();
     bool bad = false;
-    for (long i = tid; i < (long)nf * p.U; i += blockDim.x) {
-        const int fl = (int)(i / p.U);
-        const long idx = f0 * (long)p.U + i;
-        const int id = sample_dir<FROM_IDS>(p.src, idx, bad);
-        int near = -1;
-        if (id >= 0) {
-            near = p.nearest[id];
-            atomicAdd(&cnt[(size_t)fl * p.n + near], 1u);
+    const long base = f0 * (long)p.U, total = (long)nf * p.U;
+    if (!FROM_IDS && (p.U & 1) == 0) {
+        // 16-byte loads: a lane takes two neighbouring users; four such pairs are in flight.
+        // (frame, pair-in-frame) of the flat pair index is tracked incrementally: no division
+        // in the loop.
+        constexpr int UN = 4;
+        const double2* mu2 = (const double2*)(p.src.mu + base);
+        const double2* mv2 = (const double2*)(p.src.mv + base);
+        int2* out2 = (int2*)(p.assign ? p.assign + base : nullptr);
+        const int ppf = p.U >> 1;                                   // pairs per frame
+        const int pairs = nf * ppf;
+        const int dq = (int)blockDim.x / ppf, dr = (int)blockDim.x % ppf;
+        int fl0 = tid / ppf, j0 = tid % ppf;
+        for (int i0 = tid; i0 < pairs; i0 += UN * (int)blockDim.x) {
+            double2 a[UN], b[UN];
+            int fl[UN];
+            int fk = fl0, jk = j0;
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                const int i = i0 + k * (int)blockDim.x;
+                fl[k] = fk;
+                if (i < pairs) { a[k] = mu2[i]; b[k] = mv2[i]; }
+                fk += dq; jk += dr;
+                if (jk >= ppf) { jk -= ppf; ++fk; }
+            }
+            fl0 = fk; j0 = jk;
+            int near[UN][2];
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                near[k][0] = near[k][1] = -1;
+                if (i0 + k * (int)blockDim.x < pairs) {
+                    const int id0 = grid_dir(a[k].x, b[k].x, p.src.W, p.src.H, bad);
+                    const int id1 = grid_dir(a[k].y, b[k].y, p.src.W, p.src.H, bad);
+                    if (id0 >= 0) near[k][0] = p.nearest[id0];
+                    if (id1 >= 0) near[k][1] = p.nearest[id1];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                const int i = i0 + k * (int)blockDim.x;
+                if (i < pairs) {
+                    unsigned* row = cnt + (size_t)fl[k] * p.n;
+                    if (near[k][0] >= 0) atomicAdd(&row[near[k][0]], 1u);
+                    if (near[k][1] >= 0) atomicAdd(&row[near[k][1]], 1u);
+                    if (out2) out2[i] = make_int2(near[k][0], near[k][1]);
+                }
+            }
         }
-        if (p.assign) p.assign[idx] = near;
+    } else {
+        for (long i = tid; i < total; i += blockDim.x) {
+            const int fl = (int)(i / p.U);
+            const long idx = base + i;
+            const int id = sample_dir<FROM_IDS>(p.src, idx, bad);
+            int near = -1;
+            if (id >= 0) {
+                near = p.nearest[id];
+                atomicAdd(&cnt[(size_t)fl * p.n + near], 1u);
+            }
+            if (p.assign) p.assign[idx] = near;
+        }
     }
     __syncthreads();
     for (int fl = wv; fl < nf; fl += NW) {
@@ -596,6 +657,100 @@ __global__ void k_spatial_u(const SpatialParams p) {
             p.ent_k[f0 + fl] = e;
             if (p.present) p.present[f0 + fl] = np;
         }
+    }
+    if (p.status) {
+        const unsigned long long anybad = __ballot(bad);
+        if (anybad && lane == 0) atomicAdd(&p.status[0], (int)__popcll(anybad));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_spatial_u_lds — k_spatial_u for plans whose nearest-tile LUT fits the LDS (40 KB at the
+// default 100x200 grid).  Measured on MI355X (scratch/stream_probe.hip): the 2-byte LUT gather
+// from global memory runs at about one lane per cycle per CU and costs 70 us of a 177 us
+// kernel, while the same stream with the LUT in LDS reaches 5.1 TB/s.  So: persistent
+// workgroups (1024 threads, 2 per CU) load the LUT into LDS once and walk the frame axis in
+// blocks of FB frames (FB * U/2 <= 2048 sample pairs, two pairs per thread, 16-byte loads).
+// Per sample: 16 B in, one ds_read_u16, one ds_add_u32, 4 B out.  Frame f of a round is reduced
+// to its entropy by wave f.  Requires an even U <= 4096 and grid samples.
+// Counts are integers <= U, so log2(v/N) is taken as lg[v] - lg[N] from an LDS table of log2(k),
+// k = 1..U, copied from a per-context table (keeps ocml's log2 out of this kernel: 64 VGPRs, no spills).
+// LDS: lut u16 [n_dirs] | lg f64 [U+1] | cnt u32 [FB][n]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int PPT = 2;
+    const int NW = blockDim.x >> 6;
+    const int FB = p.FPW;                                                        // frames per round
+    const long D = p.src.n_dirs;
+    uint16_t* lut = (uint16_t*)smem;
+    double* lg = (double*)(smem + ((D * 2 + 15) & ~15L));                        // [U+1]
+    unsigned* cnt = (unsigned*)(lg + p.U + 1);                                   // [FB][n]
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    for (long i = tid; i < (D + 1) / 2; i += blockDim.x) ((unsigned*)lut)[i] = ((const unsigned*)p.nearest)[i];
+    for (int i = tid; i <= p.U; i += blockDim.x) lg[i] = p.log2_tab[i];
+    for (int i = tid; i < FB * p.n; i += blockDim.x) cnt[i] = 0u;
+    __syncthreads();
+    bool bad = false;
+    const int ppf = p.U >> 1;                                                    // pairs per frame
+    const float inv_ppf = 1.0f / (float)ppf;
+    const long nblocks = ((long)p.T + FB - 1) / FB;
+    for (long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const long f0 = blk * FB;
+        const int nf = (int)min((long)FB, (long)p.T - f0);
+        const int npairs = nf * ppf;
+        const double2* mu2 = (const double2*)(p.src.mu + f0 * (long)p.U);
+        const double2* mv2 = (const double2*)(p.src.mv + f0 * (long)p.U);
+        int2* out2 = (int2*)(p.assign ? p.assign + f0 * (long)p.U : nullptr);
+        double2 a[PPT], b[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = tid + k * (int)blockDim.x;
+            if (i < npairs) { a[k] = mu2[i]; b[k] = mv2[i]; }
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = tid + k * (int)blockDim.x;
+            if (i < npairs) {
+                const int fl = (int)(((float)i + 0.5f) * inv_ppf);               // exact: i < 2^12
+                const int id0 = grid_dir(a[k].x, b[k].x, p.src.W, p.src.H, bad);
+                const int id1 = grid_dir(a[k].y, b[k].y, p.src.W, p.src.H, bad);
+                const int n0 = id0 >= 0 ? (int)lut[id0] : -1;
+                const int n1 = id1 >= 0 ? (int)lut[id1] : -1;
+                unsigned* row = cnt + (size_t)fl * p.n;
+                if (n0 >= 0) atomicAdd(&row[n0], 1u);
+                if (n1 >= 0) atomicAdd(&row[n1], 1u);
+                if (out2) out2[i] = make_int2(n0, n1);
+            }
+        }
+        __syncthreads();
+        // entropy (entropy_utils.py:194-211): wave f reduces frame f and clears its histogram
+        for (int f = wv; f < nf; f += NW) {
+            unsigned* row = cnt + (size_t)f * p.n;
+            int np = 0;                            // users present = histogram total (exact)
+            for (int t = lane; t < p.n; t += WAVE) np += (int)row[t];
+            np = wave_sum(np);
+            const double tw = (double)np, lgn = lg[np], inv_tw = 1.0 / tw;
+            double h = 0.0;
+            for (int t = lane; t < p.n; t += WAVE) {
+                const unsigned v = row[t];
+                if (v) h -= ((double)v * inv_tw) * (lg[v] - lgn);
+                row[t] = 0u;
+            }
+            h = wave_sum(h);
+            if (lane == 0) {
+                double hmax = p.hmax;              // entropy_utils.py:201-206
+                if (!(tw > (double)p.n)) hmax = -tw * (1.0 / tw) * -lgn;      // log2(1/N) = -log2 N
+                double e = h / hmax;
+                if (np == 0) {
+                    e = __builtin_nan("");
+                    if (p.status) atomicAdd(&p.status[1], 1);
+                }
+                p.ent_k[f0 + f] = e;
+                if (p.present) p.present[f0 + f] = np;
+            }
+        }
+        __syncthreads();
     }
     if (p.status) {
         const unsigned long long anybad = __ballot(bad);
@@ -744,6 +899,12 @@ __global__ void k_transition(const TransParams p) {
         const unsigned long long anybad = __ballot(bad);
         if (anybad && lane == 0) atomicAdd(&p.status[0], (int)__popcll(anybad));
     }
+}
+
+// log2(k) for k = 1..n-1 (entry 0 = 0): integer-count entropies look their logarithms up
+__global__ void k_log2_table(double* __restrict__ tab, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) tab[i] = i ? log2((double)i) : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------
