@@ -399,7 +399,9 @@ int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, dou
         p.common = k == 0 ? d_common : nullptr;
         p.status = k == 0 ? d_status : nullptr;
         p.HS = HS; p.hs_shift = 32 - lg;
-        const int threads = U >= 512 ? 512 : 256;
+        p.log2_tab = c->d_log2;
+        int threads = U > 1024 ? 512 : 256;      // measured: 256 is best at U = 512 (profiles/r01)
+        if (const char* e = getenv("VET_T_THREADS")) threads = atoi(e);
         ProfScope ps(c, s, KID_TRANSITION);
         hipLaunchKernelGGL((vet::k_transition<FROM_IDS>), dim3(R), dim3(threads), lds, s, p);
         HIP_TRY(hipGetLastError());

@@ -782,6 +782,7 @@ struct TransParams {
     int32_t* srccount;            // [(T-1)*n] or null
     int32_t* common;              // [T-1] or null
     int32_t* status;
+    const double* log2_tab;       // [4097] log2(k)
     int HS;                       // hash slots (power of two >= 2*U)
     int hs_shift;                 // 32 - log2(HS)
 };
@@ -864,15 +865,18 @@ __global__ void k_transition(const TransParams p) {
     }
     __syncthreads();
 
+    // cell = -(m/N) * K * (w/m) * log2(w/m) = -(K w / N) (log2 w - log2 m): m cancels, and the
+    // logarithms of the integer counts come from the per-context table (U <= 4096)
     double h = 0.0;
+    const double inv_n = 1.0 / (double)N;
+    const bool tab = p.U <= 4096;
     for (int t = tid; t < p.n; t += blockDim.x) {
         const unsigned m = m_cnt[t];
         if (m) {
             const unsigned K = 1u + k_cnt[t];
             const unsigned w = (m == 1u) ? 1u : w_last[t];
-            const double q = (double)w / (double)m;
-            const double prop = (double)m / (double)N;
-            h += -prop * ((double)K * (q * log2(q)));
+            const double lq = tab ? p.log2_tab[w] - p.log2_tab[m] : log2((double)w / (double)m);
+            h -= ((double)(K * w) * inv_n) * lq;
         }
         if (p.srccount) p.srccount[r * (long)p.n + t] = (int)m;
     }
@@ -885,7 +889,7 @@ __global__ void k_transition(const TransParams p) {
         double hmax = p.hmax;
         if (!(N > p.n)) {
             const double tp = 1.0 / (double)N;          // entropy_utils.py:322-327
-            hmax = (double)N * -tp * log2(tp);
+            hmax = (double)N * -tp * (tab ? -p.log2_tab[N] : log2(tp));
         }
         double e = tot / hmax;
         if (N == 0) {
