@@ -72,28 +72,47 @@ def build_dense(tracks: Sequence[Tuple[np.ndarray, np.ndarray, np.ndarray]]):
     if not tracks:
         raise ValidationError("No trajectory data provided")
     known = np.empty(0, dtype=np.int64)           # frame keys in first-appearance order
+    known_sorted = known
     per_user = []
     for time, _, _ in tracks:
         keys = frame_keys(time)
-        uniq, first = np.unique(keys, return_index=True)
-        uniq = uniq[np.argsort(first, kind="stable")]           # this user's first-appearance order
-        if len(known):
-            uniq = uniq[~np.isin(uniq, known)]
-        known = np.concatenate([known, uniq])
-        per_user.append(keys)
+        increasing = len(keys) < 2 or bool(np.all(keys[1:] > keys[:-1]))
+        if increasing:                            # common case: one row per frame, in time order
+            uniq = keys
+            same = len(uniq) == len(known_sorted) and bool(np.array_equal(uniq, known_sorted))
+        else:
+            uniq, first = np.unique(keys, return_index=True)
+            same = len(uniq) == len(known_sorted) and bool(np.array_equal(uniq, known_sorted))
+            if not same:
+                uniq = uniq[np.argsort(first, kind="stable")]       # this user's first-appearance order
+        if not same:
+            if len(known):
+                uniq = uniq[~np.isin(uniq, known_sorted, assume_unique=True)]
+            if len(uniq):
+                known = np.concatenate([known, uniq])
+                known_sorted = np.sort(known)
+        per_user.append((keys, increasing))
     T, U = len(known), len(tracks)
     order = np.argsort(known, kind="stable")
     sorted_keys = known[order]
-    mu = np.full((T, U), np.nan)
-    mv = np.full((T, U), np.nan)
-    for u, ((_, a, b), keys) in enumerate(zip(tracks, per_user)):
+    # filled user-major (contiguous writes per track), transposed to frame-major once at the end
+    mu = np.full((U, T), np.nan)
+    mv = np.full((U, T), np.nan)
+    for u, ((_, a, b), (keys, increasing)) in enumerate(zip(tracks, per_user)):
         frame = order[np.searchsorted(sorted_keys, keys)]
+        a = np.asarray(a, dtype=np.float64)
+        b = np.asarray(b, dtype=np.float64)
+        if increasing:                            # no duplicate frames for this user
+            mu[u, frame] = a
+            mv[u, frame] = b
+            continue
         # last row of a frame wins: walk reversed, keep first occurrence
-        rev = frame[::-1]
-        _, idx = np.unique(rev, return_index=True)
+        _, idx = np.unique(frame[::-1], return_index=True)
         rows = len(frame) - 1 - idx
-        mu[frame[rows], u] = np.asarray(a, dtype=np.float64)[rows]
-        mv[frame[rows], u] = np.asarray(b, dtype=np.float64)[rows]
+        mu[u, frame[rows]] = a[rows]
+        mv[u, frame[rows]] = b[rows]
+    mu = np.ascontiguousarray(mu.T)
+    mv = np.ascontiguousarray(mv.T)
     return known.astype(np.float64) / 10.0, mu, mv
 
 
