@@ -403,7 +403,7 @@ int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, dou
         int threads = U > 1024 ? 512 : 256;      // measured: 256 is best at U = 512 (profiles/r01)
         if (const char* e = getenv("VET_T_THREADS")) threads = atoi(e);
         ProfScope ps(c, s, KID_TRANSITION);
-        hipLaunchKernelGGL((vet::k_transition<FROM_IDS>), dim3(R), dim3(threads), lds, s, p);
+        hipLaunchKernelGGL((vet::k_transition<FROM_IDS>), dim3(8 * ((R + 7) / 8)), dim3(threads), lds, s, p);
         HIP_TRY(hipGetLastError());
     }
     if (K > 1) {

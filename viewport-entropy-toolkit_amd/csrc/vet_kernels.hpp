@@ -803,7 +803,12 @@ __global__ void k_transition(const TransParams p) {
     unsigned* pc = hcnt + p.HS;                    // [U]
 
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id(), NW = blockDim.x >> 6;
-    const long r = blockIdx.x;                     // output row: frames r (prior) and r+1 (current)
+    // output row r compares frames r (prior) and r+1 (current).  Frame r+1 is read again by row
+    // r+1: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous run of
+    // rows — the second read then comes from that XCD's L2 (placement only affects speed).
+    const long rows_per_xcd = (p.T - 1 + 7) / 8;
+    const long r = (long)(blockIdx.x & 7) * rows_per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= rows_per_xcd || r >= p.T - 1) return;
     for (int i = tid; i < p.n; i += blockDim.x) {
         first_u[i] = 0xFFFFFFFFu; m_cnt[i] = 0; k_cnt[i] = 0; last_fu[i] = 0; w_last[i] = 0;
     }
