@@ -62,8 +62,8 @@ struct vet_ctx {
     bool profiling = false;
     std::vector<EventPair> pending;
     std::vector<hipEvent_t> free_events;
-    double prof_ms[KID_COUNT] = {0, 0, 0, 0, 0, 0};
-    int64_t prof_n[KID_COUNT] = {0, 0, 0, 0, 0, 0};
+    double prof_ms[KID_COUNT] = {};
+    int64_t prof_n[KID_COUNT] = {};
 };
 
 struct Lattice {
@@ -303,9 +303,11 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
             q.src = src; q.U = U; q.T = T;
             q.nearest = L.d_nearest; q.tab_w = L.d_tab_w; q.tab_i = L.d_tab_i; q.tab_len = L.d_tab_len; q.stride = L.stride;
             // lane group per row: 32 lanes unless the rows are tiny (measured: profiles/r01 sweep)
-            q.gs_log2 = L.stride > 16 ? 5 : 4;
+            // 4 entries per lane; 16-lane groups and 2 rows in flight per group measured best
+            // (profiles/r01/v4_table_vs_xcd_partition_sweep.log)
+            q.gs_log2 = L.stride > 32 ? 4 : 3;
             if (const char* e = getenv("VET_GS_LOG2")) q.gs_log2 = atoi(e);
-            int un = 8;
+            int un = 2;
             if (const char* e = getenv("VET_UN")) un = atoi(e);
             q.n = L.n; q.hmax = L.hmax;
             q.ent_k = p.ent_k; q.assign = p.assign; q.weights = p.weights; q.present = p.present; q.status = p.status;
@@ -325,8 +327,8 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
             int threads = 256;
             if (const char* e = getenv("VET_LUT_THREADS")) threads = atoi(e);
             if (un == 8) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 8>), dim3(blocks), dim3(threads), lds, s, q);
-            else if (un == 2) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2>), dim3(blocks), dim3(threads), lds, s, q);
-            else hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 4>), dim3(blocks), dim3(threads), lds, s, q);
+            else if (un == 4) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 4>), dim3(blocks), dim3(threads), lds, s, q);
+            else hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2>), dim3(blocks), dim3(threads), lds, s, q);
             HIP_TRY(hipGetLastError());
             continue;
         }
@@ -623,8 +625,8 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
             PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<false>(wm, R), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
             PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<true>(wm, R), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
         }
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));

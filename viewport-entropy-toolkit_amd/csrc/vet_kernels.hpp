@@ -449,6 +449,55 @@ __global__ void k_wtab(const WtabParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Row walk shared by the table kernels: the workgroup adds the ELL rows of the directions
+// fids[0..nu) into the LDS histogram hrow.  A group of GS = 2^gs_log2 lanes walks one row
+// (coalesced u32 + u16 loads); UN rows per group are in flight; rows are zero padded, so a
+// group walks to the longest of its UN rows only.
+// ------------------------------------------------------------------------------------------
+template <int UN>
+__device__ __forceinline__ void walk_rows(const int* fids, int nu, unsigned long long* hrow,
+                                          const uint32_t* __restrict__ tab_w, const uint16_t* __restrict__ tab_i,
+                                          const uint16_t* __restrict__ tab_len, int stride, int gs_log2) {
+    // every lane takes 4 consecutive entries: one 16-byte load of weights, one 8-byte load of tiles
+    // (stride is a multiple of 16 entries, so rows are 64 / 32 byte aligned)
+    const int NW = blockDim.x >> 6, lane = lane_id(), wv = wave_id();
+    const int GS = 1 << gs_log2, UPW = WAVE >> gs_log2;
+    const int sub = lane >> gs_log2, sl = lane & (GS - 1);
+    const int step = NW * UPW;
+    for (int j0 = wv * UPW; j0 < nu; j0 += UN * step) {
+        long row[UN];
+        bool on[UN];
+        int longest = 0;
+#pragma unroll
+        for (int k = 0; k < UN; ++k) {
+            const int j = j0 + k * step + sub;
+            on[k] = j < nu;
+            const int id = on[k] ? fids[j] : 0;
+            row[k] = (long)id * stride;
+            longest = max(longest, on[k] ? (int)tab_len[id] : 0);
+        }
+        for (int e = 4 * sl; e < longest; e += 4 * GS) {
+            uint4 w[UN];
+            ushort4 t[UN];
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                w[k] = *(const uint4*)(tab_w + row[k] + e);
+                t[k] = *(const ushort4*)(tab_i + row[k] + e);
+            }
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                if (on[k]) {
+                    if (w[k].x) atomicAdd(&hrow[t[k].x], (unsigned long long)w[k].x);
+                    if (w[k].y) atomicAdd(&hrow[t[k].y], (unsigned long long)w[k].y);
+                    if (w[k].z) atomicAdd(&hrow[t[k].z], (unsigned long long)w[k].z);
+                    if (w[k].w) atomicAdd(&hrow[t[k].w], (unsigned long long)w[k].w);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_spatial_lut — compute_spatial_entropy (entropy_utils.py:147-211), FoV-weighted mode, through
 // the direction weight table.  FPW frames per workgroup.
 // LDS:  hist u64 [FPW][n]   per-frame tile weight sums (units of 2^-32)
@@ -480,20 +529,16 @@ struct LutParams {
 template <bool FROM_IDS, int UN>
 __global__ void k_spatial_lut(const LutParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int NW = blockDim.x >> 6;
     unsigned long long* hist = (unsigned long long*)smem;                        // [FPW][n]
     int* ids = (int*)(hist + (size_t)p.FPW * p.n);                               // [FPW][UC]
     int* cnt_chunk = ids + (size_t)p.FPW * p.UC;                                 // [FPW]
     int* cnt_frame = cnt_chunk + p.FPW;                                          // [FPW]
-    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int tid = threadIdx.x, lane = lane_id();
     const long f0 = (long)blockIdx.x * p.FPW;
     const int nf = (int)min((long)p.FPW, (long)p.T - f0);
     for (int i = tid; i < p.FPW * p.n; i += blockDim.x) hist[i] = 0ull;
     for (int i = tid; i < 2 * p.FPW; i += blockDim.x) cnt_chunk[i] = 0;
     bool bad = false;
-    const int GS = 1 << p.gs_log2, UPW = WAVE >> p.gs_log2;
-    const int sub = lane >> p.gs_log2, sl = lane & (GS - 1);
-
     for (int u0 = 0; u0 < p.U; u0 += p.UC) {
         const int uc = min(p.UC, p.U - u0);
         __syncthreads();
@@ -508,36 +553,9 @@ __global__ void k_spatial_lut(const LutParams p) {
         }
         __syncthreads();
         for (int i = tid; i < p.FPW; i += blockDim.x) cnt_frame[i] += cnt_chunk[i];
-        for (int fl = 0; fl < nf; ++fl) {
-            const int nu = cnt_chunk[fl];
-            const int* fids = ids + (size_t)fl * p.UC;
-            unsigned long long* hrow = hist + (size_t)fl * p.n;
-            const int step = NW * UPW;
-            for (int j0 = wv * UPW; j0 < nu; j0 += UN * step) {
-                long row[UN];
-                bool on[UN];
-                int longest = 0;                        // rows are zero padded: walk to the longest only
-#pragma unroll
-                for (int k = 0; k < UN; ++k) {
-                    const int j = j0 + k * step + sub;
-                    on[k] = j < nu;
-                    const int id = on[k] ? fids[j] : 0;
-                    row[k] = (long)id * p.stride;
-                    longest = max(longest, on[k] ? (int)p.tab_len[id] : 0);
-                }
-                for (int e = sl; e < longest; e += GS) {
-                    unsigned w[UN], t[UN];
-#pragma unroll
-                    for (int k = 0; k < UN; ++k) {
-                        w[k] = p.tab_w[row[k] + e];
-                        t[k] = p.tab_i[row[k] + e];
-                    }
-#pragma unroll
-                    for (int k = 0; k < UN; ++k)
-                        if (on[k] && w[k]) atomicAdd(&hrow[t[k]], (unsigned long long)w[k]);
-                }
-            }
-        }
+        for (int fl = 0; fl < nf; ++fl)
+            walk_rows<UN>(ids + (size_t)fl * p.UC, cnt_chunk[fl], hist + (size_t)fl * p.n, p.tab_w, p.tab_i,
+                          p.tab_len, p.stride, p.gs_log2);
     }
     __syncthreads();
     weighted_frame_entropy(hist, cnt_frame, nf, f0, p.n, 4294967296.0, p.hmax, p.ent_k, p.weights, p.present,
