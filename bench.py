@@ -141,6 +141,15 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kname = "k_spatial" if mode == "spatial" else "k_transition"
+    if mode == "transition":
+        formulation = "k_transition: nearest-tile LUT gather + LDS bucket statistics"
+    elif not weighted:
+        formulation = "k_spatial_u(_lds): nearest-tile LUT + integer histogram stream"
+    elif plan.table_stride(0) > 0:
+        formulation = (f"k_spatial_lut: direction weight table gather (rows of {plan.table_stride(0)} entries, "
+                       f"{len(tcs)} lattice(s) fused in one launch)")
+    else:
+        formulation = "k_spatial_w: brute-force FP64 sweep"
     k_ms, k_n = eng.profile_get(kname)
     fin_ms, fin_n = eng.profile_get("k_finalize")
     eng.profile_enable(False)
@@ -156,13 +165,12 @@ def main():
     if rank == 0:
         samples_per_step = U * T * world
         ms_per_step = elapsed / args.steps * 1e3
-        # algorithmic bytes per k_* launch: 16 B in + 4 B (8 B transition) out per
-        # sample, 8 B entropy per frame; with K lattices the samples are re-read K times but the
-        # nearest-tile output is written once
-        K = len(tcs)
+        # algorithmic bytes: 16 B in + 4 B (8 B transition) out per sample and 8 B of
+        # entropy per frame, the samples counted once whatever the number of lattices; per launch of
+        # the dominant kernel = per step / launches per step
         per_sample_out = 4 if mode == "spatial" else 8
-        launches_per_step = K
-        alg_bytes_step = (16 * K + per_sample_out) * U * T + 8 * R * K
+        alg_bytes_step = (16 + per_sample_out) * U * T + 8 * R
+        launches_per_step = max(k_n / args.steps, 1.0)
         alg_bytes_launch = alg_bytes_step / launches_per_step
         avg_kernel_ms = k_ms / max(k_n, 1)
         achieved = alg_bytes_launch / (avg_kernel_ms * 1e-3) / 1e9 if k_n else None
@@ -187,10 +195,12 @@ def main():
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "avg_kernel_ms": avg_kernel_ms, "launches": k_n,
-                         "note": "weighted FoV histogram is FP64-VALU-bound (acos/pow per in-FoV tile), "
-                                 "not HBM-bound; see DESIGN.md" if (mode == "spatial" and weighted) else
-                                 "integer histogram path"},
+                         "note": ("weighted FoV histogram: the table gather moves ~6*stride B/sample from L2/"
+                                  "Infinity Cache on top of the algorithmic bytes; bound by gather bandwidth, "
+                                  "not HBM (DESIGN.md §5)") if (mode == "spatial" and weighted) else
+                                 "integer histogram stream: HBM-bound"},
             "kernel_ms_per_step": {kname: k_ms / args.steps, "k_finalize": fin_ms / args.steps},
+            "formulation": formulation,
             "plan_build_ms": plan_ms,
         }
         if world == 1 and not args.no_cpu_baseline:

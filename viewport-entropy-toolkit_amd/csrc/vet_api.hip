@@ -262,13 +262,63 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
     vet_ctx* c = pl->ctx;
     const int K = (int)pl->lat.size();
     double* ent_k = d_entropy;
+    int ubits = 0;
+    while ((1L << ubits) < (long)U) ++ubits;
+    // ---- weighted, table formulation: every lattice in one launch
+    if (want_table(pl, U, T) && K <= vet::MAX_LATTICES) {
+        bool ok = true;
+        for (int k = 0; k < K; ++k) {
+            int rc = ensure_wtab(pl, k, s);
+            if (rc) return rc;
+            ok = ok && pl->lat[k].stride > 0;
+        }
+        if (ok) {
+            vet::LutParams q;
+            q.src = src; q.U = U; q.T = T;
+            q.nearest = pl->lat[0].d_nearest;
+            q.K = K; q.n_sum = 0;
+            for (int k = 0; k < K; ++k) {
+                const Lattice& L = pl->lat[k];
+                q.lat[k].tab_w = L.d_tab_w; q.lat[k].tab_i = L.d_tab_i; q.lat[k].tab_len = L.d_tab_len;
+                q.lat[k].stride = L.stride;
+                // 4 entries per lane; 16-lane groups and 2 rows in flight per group measured best
+                // (profiles/r01/v4_table_vs_xcd_partition_sweep.log)
+                q.lat[k].gs_log2 = L.stride > 32 ? 4 : 3;
+                if (const char* e = getenv("VET_GS_LOG2")) q.lat[k].gs_log2 = atoi(e);
+                q.lat[k].n = L.n; q.lat[k].hmax = L.hmax;
+                q.n_sum += L.n;
+            }
+            q.entropy = d_entropy; q.assign = d_assign; q.weights = d_weights; q.present = d_present;
+            q.status = d_status;
+            // geometry: enough frames per workgroup to give every wave >= 8 users
+            q.UC = U < 2048 ? U : 2048;
+            int fpw = U >= 256 ? 1 : (U >= 64 ? 4 : 16);
+            size_t lds = 0;
+            for (;; fpw /= 2) {
+                lds = (size_t)fpw * q.n_sum * 8 + (size_t)fpw * q.UC * 4 + (size_t)2 * fpw * 4 + 64;
+                if (lds <= c->lds_max || fpw == 1) break;
+            }
+            if (lds <= c->lds_max) {
+                q.FPW = fpw;
+                const int blocks = (T + fpw - 1) / fpw;
+                int un = 2;
+                if (const char* e = getenv("VET_UN")) un = atoi(e);
+                int threads = 256;
+                if (const char* e = getenv("VET_LUT_THREADS")) threads = atoi(e);
+                ProfScope ps(c, s, KID_SPATIAL);
+                if (un == 8) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 8>), dim3(blocks), dim3(threads), lds, s, q);
+                else if (un == 4) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 4>), dim3(blocks), dim3(threads), lds, s, q);
+                else hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2>), dim3(blocks), dim3(threads), lds, s, q);
+                HIP_TRY(hipGetLastError());
+                return VET_OK;
+            }
+        }
+    }
     if (K > 1) {
         int rc = ensure_ws(c, (size_t)K * T * sizeof(double));
         if (rc) return rc;
         ent_k = (double*)c->ws;
     }
-    int ubits = 0;
-    while ((1L << ubits) < (long)U) ++ubits;
     for (int k = 0; k < K; ++k) {
         const Lattice& L = pl->lat[k];
         Geometry g;
@@ -294,44 +344,6 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         p.status = k == 0 ? d_status : nullptr;
         p.FPW = g.FPW; p.G = g.G; p.UC = g.UC;
         p.log2_tab = c->d_log2;
-        if (want_table(pl, U, T)) {
-            rc = ensure_wtab(pl, k, s);
-            if (rc) return rc;
-        }
-        if (pl->weighted && pl->lat[k].stride > 0 && want_table(pl, U, T)) {
-            vet::LutParams q;
-            q.src = src; q.U = U; q.T = T;
-            q.nearest = L.d_nearest; q.tab_w = L.d_tab_w; q.tab_i = L.d_tab_i; q.tab_len = L.d_tab_len; q.stride = L.stride;
-            // lane group per row: 32 lanes unless the rows are tiny (measured: profiles/r01 sweep)
-            // 4 entries per lane; 16-lane groups and 2 rows in flight per group measured best
-            // (profiles/r01/v4_table_vs_xcd_partition_sweep.log)
-            q.gs_log2 = L.stride > 32 ? 4 : 3;
-            if (const char* e = getenv("VET_GS_LOG2")) q.gs_log2 = atoi(e);
-            int un = 2;
-            if (const char* e = getenv("VET_UN")) un = atoi(e);
-            q.n = L.n; q.hmax = L.hmax;
-            q.ent_k = p.ent_k; q.assign = p.assign; q.weights = p.weights; q.present = p.present; q.status = p.status;
-            // geometry: 8 waves; enough frames per workgroup to give every wave >= 8 users
-            q.UC = U < 2048 ? U : 2048;
-            int fpw = U >= 256 ? 1 : (U >= 64 ? 4 : 16);
-            size_t lds = 0;
-            for (;; fpw /= 2) {
-                lds = (size_t)fpw * L.n * 8 + (size_t)fpw * q.UC * 4 + (size_t)2 * fpw * 4 + 64;
-                if (lds <= c->lds_max || fpw == 1) break;
-            }
-            if (lds > c->lds_max)
-                return fail(VET_ERR_UNSUPPORTED, "lattice of %d tiles does not fit the LDS histogram (%zu B)", L.n, lds);
-            q.FPW = fpw;
-            const int blocks = (T + fpw - 1) / fpw;
-            ProfScope ps(c, s, KID_SPATIAL);
-            int threads = 256;
-            if (const char* e = getenv("VET_LUT_THREADS")) threads = atoi(e);
-            if (un == 8) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 8>), dim3(blocks), dim3(threads), lds, s, q);
-            else if (un == 4) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 4>), dim3(blocks), dim3(threads), lds, s, q);
-            else hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2>), dim3(blocks), dim3(threads), lds, s, q);
-            HIP_TRY(hipGetLastError());
-            continue;
-        }
         if (!pl->weighted && !FROM_IDS && (U & 1) == 0 && U <= 4096 && !p.weights && !getenv("VET_U_NO_LDS")) {
             // persistent variant with the nearest LUT in LDS: FB frames x U/2 pairs <= 2048 per round
             constexpr int THREADS = 1024;

@@ -507,36 +507,46 @@ __device__ __forceinline__ void walk_rows(const int* fids, int nu, unsigned long
 // non-zero entries into the frame histogram with ds_add_u64; a wave serves 64/GS users at once
 // and two such steps are issued back to back to keep more loads in flight.
 // ------------------------------------------------------------------------------------------
-struct LutParams {
-    SampleSrc src;
-    int U, T;
-    const uint16_t* nearest;
+constexpr int MAX_LATTICES = 8;
+
+struct LutLattice {
     const uint32_t* tab_w;
     const uint16_t* tab_i;
     const uint16_t* tab_len;
-    int stride;
-    int gs_log2;
-    int n;
+    int stride, gs_log2, n;
     double hmax;
-    double* ent_k;
+};
+
+struct LutParams {
+    SampleSrc src;
+    int U, T;
+    const uint16_t* nearest;      // lattice 0 (assign)
+    int K;                        // lattices handled by this launch (<= MAX_LATTICES)
+    int n_sum;                    // sum of n over the K lattices
+    LutLattice lat[MAX_LATTICES];
+    double* entropy;              // [T] mean over the K lattices, summed in order
     int32_t* assign;
-    double* weights;
+    double* weights;              // lattice 0
     int32_t* present;
     int32_t* status;
     int FPW, UC;
 };
 
+// All K lattices of the plan in one launch: the samples are read once, every user's K rows are
+// gathered into K histograms, and avg_entropy = (e_0 + ... + e_{K-1}) / K is formed in lattice
+// order as the reference does (spatial_entropy.py:142-156) — no per-lattice pass, no finalize.
 template <bool FROM_IDS, int UN>
 __global__ void k_spatial_lut(const LutParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* hist = (unsigned long long*)smem;                        // [FPW][n]
-    int* ids = (int*)(hist + (size_t)p.FPW * p.n);                               // [FPW][UC]
+    unsigned long long* hist = (unsigned long long*)smem;                        // [FPW][n_sum]
+    int* ids = (int*)(hist + (size_t)p.FPW * p.n_sum);                           // [FPW][UC]
     int* cnt_chunk = ids + (size_t)p.FPW * p.UC;                                 // [FPW]
     int* cnt_frame = cnt_chunk + p.FPW;                                          // [FPW]
-    const int tid = threadIdx.x, lane = lane_id();
+    const int NW = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const long f0 = (long)blockIdx.x * p.FPW;
     const int nf = (int)min((long)p.FPW, (long)p.T - f0);
-    for (int i = tid; i < p.FPW * p.n; i += blockDim.x) hist[i] = 0ull;
+    for (int i = tid; i < p.FPW * p.n_sum; i += blockDim.x) hist[i] = 0ull;
     for (int i = tid; i < 2 * p.FPW; i += blockDim.x) cnt_chunk[i] = 0;
     bool bad = false;
     for (int u0 = 0; u0 < p.U; u0 += p.UC) {
@@ -553,13 +563,51 @@ __global__ void k_spatial_lut(const LutParams p) {
         }
         __syncthreads();
         for (int i = tid; i < p.FPW; i += blockDim.x) cnt_frame[i] += cnt_chunk[i];
-        for (int fl = 0; fl < nf; ++fl)
-            walk_rows<UN>(ids + (size_t)fl * p.UC, cnt_chunk[fl], hist + (size_t)fl * p.n, p.tab_w, p.tab_i,
-                          p.tab_len, p.stride, p.gs_log2);
+        for (int fl = 0; fl < nf; ++fl) {
+            unsigned long long* hrow = hist + (size_t)fl * p.n_sum;
+            for (int k = 0; k < p.K; ++k) {
+                const LutLattice& L = p.lat[k];
+                walk_rows<UN>(ids + (size_t)fl * p.UC, cnt_chunk[fl], hrow, L.tab_w, L.tab_i, L.tab_len, L.stride,
+                              L.gs_log2);
+                hrow += L.n;
+            }
+        }
     }
     __syncthreads();
-    weighted_frame_entropy(hist, cnt_frame, nf, f0, p.n, 4294967296.0, p.hmax, p.ent_k, p.weights, p.present,
-                           p.status);
+    // entropy (entropy_utils.py:194-211, weighted: normaliser log2 n); wave w takes frames w, w+NW, ...
+    for (int fl = wv; fl < nf; fl += NW) {
+        const unsigned long long* hrow = hist + (size_t)fl * p.n_sum;
+        double total_entropy = 0.0;
+        for (int k = 0; k < p.K; ++k) {
+            const int n = p.lat[k].n;
+            // total weight can exceed 64 bits of fixed point: summed in FP64, fixed lane order + butterfly
+            double totd = 0.0;
+            for (int t = lane; t < n; t += WAVE) totd += (double)hrow[t];
+            totd = wave_sum(totd);
+            double h = 0.0;
+            for (int t = lane; t < n; t += WAVE) {
+                const unsigned long long v = hrow[t];
+                if (v) {
+                    const double q = (double)v / totd;
+                    h -= q * log2(q);
+                }
+                if (k == 0 && p.weights) p.weights[(f0 + fl) * (long)n + t] = (double)v / 4294967296.0;
+            }
+            h = wave_sum(h);
+            total_entropy += h / p.lat[k].hmax;
+            hrow += n;
+        }
+        if (lane == 0) {
+            const int np = cnt_frame[fl];
+            double e = total_entropy / (double)p.K;
+            if (np == 0) {
+                e = __builtin_nan("");
+                if (p.status) atomicAdd(&p.status[1], 1);
+            }
+            p.entropy[f0 + fl] = e;
+            if (p.present) p.present[f0 + fl] = np;
+        }
+    }
     if (p.status) {
         const unsigned long long anybad = __ballot(bad);
         if (anybad && lane == 0) atomicAdd(&p.status[0], (int)__popcll(anybad));
