@@ -1,0 +1,119 @@
+"""GPU: odd shapes and sizes against the oracle — user counts that exercise the LDS chunking,
+odd / tiny user counts, 1-frame videos, the reference's five default lattices in one call, tiny
+and large pixel grids, large transition frames, absent users everywhere."""
+import numpy as np
+import pytest
+
+from oracle import vet_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from viewport_entropy_toolkit import _native
+    return _native
+
+
+@pytest.fixture(scope="module")
+def engine(native):
+    return native.Engine.default()
+
+
+def video(U, T, seed, p_absent=0.1):
+    rng = np.random.default_rng(seed)
+    mu = np.mod(0.5 + np.cumsum(rng.normal(0, 0.02, (T, U)), axis=0) + rng.random((1, U)), 1.0)
+    mv = np.clip(0.5 + np.cumsum(rng.normal(0, 0.01, (T, U)), axis=0) + rng.normal(0, 0.2, (1, U)), 0.0, 1.0)
+    gone = rng.random((T, U)) < p_absent
+    gone[np.arange(T), rng.integers(0, U, T)] = False
+    mu[gone] = np.nan
+    mv[gone] = np.nan
+    return mu, mv
+
+
+def plan_for(native, engine, tcs, W=100, H=200, weighted=True, policy=0, **kw):
+    plan = native.Plan(engine, [vo.fibonacci_lattice(tc) for tc in tcs], kw.get("fov", 120.0), kw.get("power", 2.0),
+                       weighted, W, H)
+    plan.set_table_policy(policy)
+    return plan
+
+
+@pytest.mark.parametrize("U,T,tcs,weighted,policy", [
+    (3000, 7, [50], True, 1),          # more users than one LDS id chunk (table formulation)
+    (2500, 5, [100], True, -1),        # more users than one LDS direction chunk (sweep formulation)
+    (3000, 6, [50], False, 0),         # unweighted, persistent LDS-LUT kernel, many users
+    (1001, 9, [50], False, 0),         # odd user count: generic unweighted kernel
+    (7, 40, [20, 50], True, 1),
+    (7, 40, [20, 50], True, -1),
+    (1, 1, [50], True, 0),
+    (2, 3, [1], True, 0),              # one-tile lattice: nan everywhere
+    (33, 17, [2], False, 0),
+    (40, 50, [20, 50, 100, 250, 1000], True, 1),     # the reference's default tile_counts, fused
+    (40, 50, [20, 50, 100, 250, 1000], True, -1),
+    (40, 50, [20, 50, 100, 250, 1000], False, 0),
+    (64, 30, [1000], True, 1),
+    (600, 4, [2000], True, -1),        # n = 2001: 16 tile groups of 128, several per wave
+])
+def test_spatial_shapes(native, engine, U, T, tcs, weighted, policy):
+    mu, mv = video(U, T, seed=U * 31 + T)
+    plan = plan_for(native, engine, tcs, weighted=weighted, policy=policy)
+    res = plan.spatial(mu=mu, mv=mv, want_weights=True)
+    ent, assign, weights = vo.spatial_series(mu, mv, 100, 200, tcs, use_weight_distribution=weighted,
+                                             want_weights=True)
+    assert np.array_equal(res["assign"], assign)
+    assert np.array_equal(res["present"], (~np.isnan(mu)).sum(1))
+    np.testing.assert_allclose(res["entropy"], ent, rtol=1e-8, equal_nan=True)
+    np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=2.0 ** -33 * U + 1e-12)
+    plan.close()
+
+
+@pytest.mark.parametrize("W,H,tc", [(6, 4, 20), (640, 480, 50), (3840, 1920, 20)])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_other_pixel_grids(native, engine, W, H, tc, weighted):
+    mu, mv = video(48, 64, seed=W + H)
+    plan = plan_for(native, engine, [tc], W, H, weighted=weighted, policy=-1 if W > 1000 else 0)
+    res = plan.spatial(mu=mu, mv=mv)
+    ent, assign, _ = vo.spatial_series(mu, mv, W, H, [tc], use_weight_distribution=weighted)
+    assert np.array_equal(res["assign"], assign)
+    np.testing.assert_allclose(res["entropy"], ent, rtol=1e-8, equal_nan=True)
+    tr = plan.transition(mu=mu, mv=mv, check=False)
+    e2, pairs = vo.transition_series(mu, mv, W, H, [tc]) if (tr["common"] > 0).all() else (None, None)
+    if e2 is not None:
+        assert np.array_equal(tr["pairs"], pairs)
+        np.testing.assert_allclose(tr["entropy"], e2, rtol=1e-9, equal_nan=True)
+    plan.close()
+
+
+@pytest.mark.parametrize("U,T,tcs", [(1500, 6, [50]), (4096, 3, [20]), (3, 30, [20, 50, 100]), (2, 2, [1000])])
+def test_transition_shapes(native, engine, U, T, tcs):
+    mu, mv = video(U, T, seed=U + 7 * T, p_absent=0.05)
+    mu[:, 0] = np.where(np.isnan(mu[:, 0]), 0.5, mu[:, 0])      # user 0 always present: no empty rows
+    mv[:, 0] = np.where(np.isnan(mv[:, 0]), 0.5, mv[:, 0])
+    plan = plan_for(native, engine, tcs)
+    res = plan.transition(mu=mu, mv=mv, want_srccount=True)
+    ent, pairs = vo.transition_series(mu, mv, 100, 200, tcs, closed_form=False)
+    assert np.array_equal(res["pairs"], pairs)
+    assert np.array_equal(res["common"], (~np.isnan(mu[1:]) & ~np.isnan(mu[:-1])).sum(1))
+    np.testing.assert_allclose(res["entropy"], ent, rtol=1e-9, equal_nan=True)
+    plan.close()
+
+
+def test_heavily_clustered_users(native, engine):
+    """Everybody looks at the same few tiles: same-address LDS atomics, buckets with many users."""
+    rng = np.random.default_rng(1)
+    U, T = 512, 40
+    mu = np.clip(0.5 + rng.normal(0, 0.004, (T, U)), 0, 1)
+    mv = np.clip(0.5 + rng.normal(0, 0.004, (T, U)), 0, 1)
+    for weighted, policy in ((True, 1), (True, -1), (False, 0)):
+        plan = plan_for(native, engine, [50, 500], weighted=weighted, policy=policy)
+        res = plan.spatial(mu=mu, mv=mv)
+        ent, assign, _ = vo.spatial_series(mu, mv, 100, 200, [50, 500], use_weight_distribution=weighted)
+        assert np.array_equal(res["assign"], assign)
+        np.testing.assert_allclose(res["entropy"], ent, rtol=1e-8)
+        plan.close()
+    plan = plan_for(native, engine, [50, 500])
+    tr = plan.transition(mu=mu, mv=mv)
+    ent, pairs = vo.transition_series(mu, mv, 100, 200, [50, 500], closed_form=False)
+    assert np.array_equal(tr["pairs"], pairs)
+    np.testing.assert_allclose(tr["entropy"], ent, rtol=1e-9)
+    plan.close()

@@ -398,9 +398,10 @@ int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, dou
     for (int k = 0; k < K; ++k) {
         const Lattice& L = pl->lat[k];
         size_t lds = 16 * 8 + 8 + (size_t)5 * L.n * 4 + (size_t)3 * HS * 4 + (size_t)U * 4 + 16;
-        if (lds > c->lds_max)
+        const size_t lds_cap = 160 * 1024 - 512;     // a single workgroup may take the whole LDS
+        if (lds > lds_cap)
             return fail(VET_ERR_UNSUPPORTED, "transition kernel: %d users x %d tiles need %zu B of LDS (max %zu)", U,
-                        L.n, lds, c->lds_max);
+                        L.n, lds, lds_cap);
         vet::TransParams p;
         p.src = src;
         p.U = U; p.T = T;
@@ -642,8 +643,8 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_transition<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_transition<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
 #undef PLAN_TRY
     *out = pl;
     return VET_OK;
