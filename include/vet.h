@@ -98,6 +98,17 @@ typedef struct vet_plan_desc {
     double max_angular_distance;    /* np.radians(fov_angle/2), entropy_utils.py:124 */
     double power_factor;            /* > 0 */
     int use_weight_distribution;
+    /* Optional "binned" lattices (NULL = none): h_bin_lut[k] != NULL replaces lattice k's
+     * nearest-tile search by a caller-supplied direction -> bin table [n_dirs] with n_tiles[k]
+     * bins (h_tiles[k] is then ignored).  This is the naive lat/lon tiling of
+     * compute_naive_spatial_entropy (utilities/entropy_utils.py:383-452): every user adds 1 to
+     * its bin; use_weight_distribution only selects the normaliser (log2 of h_max_entropy's n
+     * always, vs. log2(users) when users <= n). */
+    const uint16_t *const *h_bin_lut;
+    /* [K] or NULL: the tile count the normaliser compares the user count with when it differs from
+     * the number of histogram bins (naive tiling: (180/h)*(360/w) tiles, but lon = 180 / lat = 90
+     * open one more bin column / row). */
+    const int *n_norm_tiles;
 } vet_plan_desc;
 
 int vet_plan_create(vet_ctx *ctx, const vet_plan_desc *desc, vet_plan **out);

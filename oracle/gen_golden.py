@@ -14,7 +14,7 @@ Fixtures:
   G1 lattices, G2 quantiser tables, G3 exhaustive nearest-tile tables,
   G4 spatial analyzer runs (config 1), G5 transition analyzer runs,
   G6 ingest edge cases, G7 per-direction weight rows, G8 dense transition
-  frames (bucket quirk exercised), G9 operator-level edge cases.
+  frames (bucket quirk exercised), G9 operator-level edge cases, G10 naive lat/lon analyzer.
 """
 
 from __future__ import annotations
@@ -467,6 +467,49 @@ def g9_operator_edges(vt):
                                      "trans_empty", "trans_disjoint")})
 
 
+
+# ----------------------------------------------------------------------------
+def g10_naive(vt, synth):
+    """Naive lat/lon-grid analyzer: analyzers/naive_spatial_entropy.py and
+    utilities/entropy_utils.py:335-452."""
+    from viewport_entropy_toolkit import NaiveSpatialEntropyAnalyzer
+    from viewport_entropy_toolkit.config import NaiveAnalyzerConfig, EntropyConfig
+    from viewport_entropy_toolkit.utilities import compute_naive_spatial_entropy
+    names, ts, mus, mvs = _config1_inputs(synth)
+    out = {"time_in": np.array(ts), "mu_in": np.array(mus), "mv_in": np.array(mvs)}
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        d = td / "video"
+        d.mkdir()
+        _write_csvs(d, ts, mus, mvs, names)
+        os.chdir(td)
+        for th, tw in ((10, 10), (30, 45), (20, 20), (90, 180)):
+            for flag in (True, False):
+                tag = f"h{th}_w{tw}_{'w' if flag else 'u'}"
+                cfg = NaiveAnalyzerConfig(output_dir=td / "out", tile_height=th, tile_width=tw,
+                                          entropy_config=EntropyConfig(use_weight_distribution=flag))
+                an = NaiveSpatialEntropyAnalyzer(cfg)
+                an.process_directory(d)
+                res = an.compute_entropy()
+                pts = an._data_cache["points"]
+                cols = [c for c in pts.columns if c != "time"]
+                out[f"{tag}__columns"] = np.array(cols)
+                out[f"{tag}__time"] = res["time"].to_numpy(dtype=np.float64)
+                out[f"{tag}__entropy"] = res["entropy"].to_numpy(dtype=np.float64)
+                out[f"{tag}__weights_is_none"] = np.array(all(w is None for w in res["tile_weights"]))
+                # operator level on three frames: weights and assignments
+                for fi in (0, 150, 299):
+                    row = pts.iloc[fi]
+                    pd_ = {c: row[c] for c in cols if row[c] is not None}
+                    e, w, a = compute_naive_spatial_entropy(pd_, th, tw, cfg.entropy_config)
+                    out[f"{tag}__f{fi}_entropy"] = np.array(e)
+                    out[f"{tag}__f{fi}_wkeys"] = np.array(sorted(w))
+                    out[f"{tag}__f{fi}_wvals"] = np.array([w[k] for k in sorted(w)])
+                    out[f"{tag}__f{fi}_assign"] = np.array([a[c] for c in cols])
+                print("G10", tag, float(res["entropy"].mean()), flush=True)
+    np.savez_compressed(OUT / "g10_naive.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -495,6 +538,8 @@ def main():
         g9_operator_edges(vt)
     if want("G8"):
         g8_dense_transition(vt, synth)
+    if want("G10"):
+        g10_naive(vt, synth)
     if want("G4"):
         g4_spatial(vt, synth)
     if want("G5"):

@@ -319,6 +319,47 @@ def transition_series(mu: np.ndarray, mv: np.ndarray, W: int, H: int, tile_count
 
 
 # --------------------------------------------------------------------------- #
+# naive lat/lon-grid tiling                            #
+# --------------------------------------------------------------------------- #
+def naive_tile_indices(lon: np.ndarray, lat: np.ndarray, tile_height, tile_width):
+    """entropy_utils.py:378-381: int((lon+180)/w), int((lat+90)/h) (truncation)."""
+    return ((np.asarray(lon) + 180) / tile_width).astype(np.int64), ((np.asarray(lat) + 90) / tile_height).astype(np.int64)
+
+
+def naive_entropy_from_counts(counts: np.ndarray, tile_height, tile_width, use_weight_distribution: bool) -> float:
+    """entropy_utils.py:425-452 given the number of users per occupied tile."""
+    counts = np.asarray(counts, dtype=np.float64)
+    counts = counts[counts > 0]
+    total = float(counts.sum())
+    num_tiles = int(180.0 / tile_height) * int(360.0 / tile_width)
+    with np.errstate(all="ignore"):
+        p = counts / total
+        ent = float(-(p * np.log2(p)).sum()) if len(p) else 0.0
+        mx = _max_entropy(num_tiles) if (use_weight_distribution or total > num_tiles) else _max_entropy(total)
+        return float(np.float64(ent) / np.float64(mx))
+
+
+def naive_series(mu: np.ndarray, mv: np.ndarray, W: int, H: int, tile_height, tile_width,
+                 use_weight_distribution: bool = True):
+    """analyzers/naive_spatial_entropy.py:102-152 on dense arrays.  Returns (entropy[T],
+    lon_idx[T][U], lat_idx[T][U]) with -1 where absent."""
+    px, py, present, _ = sample_directions(mu, mv, W, H)
+    lon_axis, lat_axis = axis_tables(W, H)
+    li_axis, lj_axis = naive_tile_indices(lon_axis, lat_axis, tile_height, tile_width)
+    T, U = mu.shape
+    li = np.where(present, li_axis[np.where(present, px, 0)], -1)
+    lj = np.where(present, lj_axis[np.where(present, py, 0)], -1)
+    ent = np.zeros(T)
+    for t in range(T):
+        if not present[t].any():
+            raise ValueError("Empty radial points dictionary")
+        keys = li[t][present[t]] * 100000 + lj[t][present[t]]
+        _, counts = np.unique(keys, return_counts=True)
+        ent[t] = naive_entropy_from_counts(counts, tile_height, tile_width, use_weight_distribution)
+    return ent, li, lj
+
+
+# --------------------------------------------------------------------------- #
 # ingest (frame index construction)                                           #
 # --------------------------------------------------------------------------- #
 def format_trajectories(tracks: List[Tuple[np.ndarray, np.ndarray, np.ndarray]]):

@@ -166,3 +166,57 @@ def test_calculate_tile_weights_rows(golden_dir):
         assert all(got[keys[k]] >= got[keys[k + 1]] for k in range(len(keys) - 1))   # ascending distance
     assert calculate_tile_weights(v, L, EntropyConfig(use_weight_distribution=False)) == \
         {L[find_nearest_tile(v, L)]: 1.0}
+
+
+# ---------------------------------------------------------------- naive lat/lon analyzer (§8f rank 3)
+@pytest.mark.parametrize("th,tw", [(10, 10), (30, 45), (20, 20), (90, 180)])
+@pytest.mark.parametrize("flag", [True, False])
+def test_naive_analyzer_vs_reference(tmp_path, golden_dir, th, tw, flag):
+    from viewport_entropy_toolkit import NaiveSpatialEntropyAnalyzer
+    from viewport_entropy_toolkit.config import NaiveAnalyzerConfig
+    from viewport_entropy_toolkit.utilities import compute_naive_spatial_entropy, find_naive_tile_index
+    g = _write_config1(golden_dir, tmp_path / "video", "g10_naive.npz")
+    tag = f"h{th}_w{tw}_{'w' if flag else 'u'}"
+    cfg = NaiveAnalyzerConfig(output_dir=tmp_path / "out", tile_height=th, tile_width=tw,
+                              entropy_config=EntropyConfig(use_weight_distribution=flag))
+    an = NaiveSpatialEntropyAnalyzer(cfg)
+    an.run_analysis(tmp_path / "video", "n")
+    res = an._entropy_results
+    assert list(res.columns) == ["time", "entropy", "tile_weights", "tile_assignments"]
+    assert np.array_equal(res["time"], g[f"{tag}__time"]) and all(w is None for w in res["tile_weights"])
+    np.testing.assert_allclose(res["entropy"], g[f"{tag}__entropy"], rtol=1e-9)
+    assert len(list((tmp_path / "out").glob("video_n_*.csv"))) == 1
+    # operator level on the frames the fixture holds
+    pts = an._data_cache["points"]
+    cols = [str(c) for c in g[f"{tag}__columns"]]
+    for fi in (0, 150, 299):
+        row = pts.iloc[fi]
+        pd_ = {c: row[c] for c in cols if row[c] is not None}
+        e, w, a = compute_naive_spatial_entropy(pd_, th, tw, cfg.entropy_config)
+        assert e == pytest.approx(float(g[f"{tag}__f{fi}_entropy"]), rel=1e-9)
+        assert [a[c] for c in cols] == [str(x) for x in g[f"{tag}__f{fi}_assign"]]
+        assert w == dict(zip([str(k) for k in g[f"{tag}__f{fi}_wkeys"]], g[f"{tag}__f{fi}_wvals"].tolist()))
+        assert find_naive_tile_index(row[cols[0]], th, tw) == a[cols[0]]
+    with pytest.raises(vt.ValidationError):
+        compute_naive_spatial_entropy({"a": vt.RadialPoint(0.0, 0.0)}, 7, 10, cfg.entropy_config)
+    with pytest.raises(vt.ValidationError):
+        compute_naive_spatial_entropy({}, 10, 10, cfg.entropy_config)
+
+
+def test_naive_config3_size_vs_oracle():
+    """Large video through the naive analyzer's engine path (persistent LDS-LUT stream kernel)."""
+    from viewport_entropy_toolkit import NaiveSpatialEntropyAnalyzer
+    from viewport_entropy_toolkit.config import NaiveAnalyzerConfig
+    rng = np.random.default_rng(3)
+    U, T = 512, 2000
+    mu = np.mod(0.5 + np.cumsum(rng.normal(0, 0.01, (T, U)), axis=0), 1.0)
+    mv = np.clip(0.5 + np.cumsum(rng.normal(0, 0.005, (T, U)), axis=0), 0.0, 1.0)
+    mu[rng.random((T, U)) < 0.05] = np.nan
+    mu[:, 0] = 0.5
+    for flag in (True, False):
+        an = NaiveSpatialEntropyAnalyzer(NaiveAnalyzerConfig(output_dir="/tmp/vet_naive_out", tile_height=10, tile_width=20,
+                                                             entropy_config=EntropyConfig(use_weight_distribution=flag)))
+        an.load_arrays(np.arange(T) * 0.1, mu, mv)
+        ent = an.compute_entropy()["entropy"].to_numpy()
+        ref, _, _ = vo.naive_series(mu, mv, 100, 200, 10, 20, flag)
+        np.testing.assert_allclose(ent, ref, rtol=1e-9)

@@ -175,3 +175,23 @@ def test_g9_operator_edges(golden_dir):
             fn([], [], len(L))
     assert str(g["spatial_empty"]) == "ValidationError"
     assert str(g["trans_disjoint"]) == "ZeroDivisionError"
+
+
+@pytest.mark.parametrize("th,tw", [(10, 10), (30, 45), (20, 20), (90, 180)])
+@pytest.mark.parametrize("flag", [True, False])
+def test_g10_naive_analyzer(golden_dir, th, tw, flag):
+    g = load(golden_dir, "g10_naive.npz")
+    tag = f"h{th}_w{tw}_{'w' if flag else 'u'}"
+    cols = [str(c) for c in g[f"{tag}__columns"]]
+    order = [int(c[4:]) for c in cols]
+    tracks = [(g["time_in"][u], g["mu_in"][u], g["mv_in"][u]) for u in order]
+    times, mu, mv = vo.format_trajectories(tracks)
+    ent, li, lj = vo.naive_series(mu, mv, 100, 200, th, tw, flag)
+    assert np.array_equal(times, g[f"{tag}__time"]) and bool(g[f"{tag}__weights_is_none"])
+    np.testing.assert_allclose(ent, g[f"{tag}__entropy"], rtol=RTOL, equal_nan=True)
+    for fi in (0, 150, 299):
+        assert [f"{a}_{b}" for a, b in zip(li[fi], lj[fi])] == [str(x) for x in g[f"{tag}__f{fi}_assign"]]
+        keys, counts = np.unique([f"{a}_{b}" for a, b in zip(li[fi], lj[fi])], return_counts=True)
+        assert sorted(keys) == [str(k) for k in g[f"{tag}__f{fi}_wkeys"]]
+        assert np.array_equal(counts[np.argsort(keys)].astype(float), g[f"{tag}__f{fi}_wvals"])
+        np.testing.assert_allclose(ent[fi], g[f"{tag}__f{fi}_entropy"], rtol=RTOL)

@@ -77,6 +77,8 @@ struct Lattice {
     uint16_t* d_tab_i = nullptr;   // [n_dirs][stride]
     uint16_t* d_tab_len = nullptr; // [n_dirs]
     int stride = 0;                // 0 = not built, -1 = not usable (too large)
+    bool binned = false;           // caller-supplied direction -> bin table (naive lat/lon tiling)
+    int norm_n = 0;                // tile count used by the normaliser rule
 };
 
 struct vet_plan {
@@ -250,8 +252,13 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     return VET_OK;
 }
 
+bool any_binned(const vet_plan* pl) {
+    for (const auto& L : pl->lat) if (L.binned) return true;
+    return false;
+}
+
 bool want_table(const vet_plan* pl, int U, int T) {
-    if (!pl->weighted || pl->table_policy < 0) return false;
+    if (!pl->weighted || pl->table_policy < 0 || any_binned(pl)) return false;
     if (pl->table_policy > 0) return true;
     return (long)U * T >= (long)pl->n_dirs;      // rows are reused on average at least once
 }
@@ -321,8 +328,10 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
     }
     for (int k = 0; k < K; ++k) {
         const Lattice& L = pl->lat[k];
+        // binned lattices (naive tiling) are always integer counts; the flag picks the normaliser
+        const bool hist_weighted = pl->weighted != 0 && !L.binned;
         Geometry g;
-        int rc = spatial_geometry(c, L.n, U, pl->weighted != 0, &g);
+        int rc = spatial_geometry(c, L.n, U, hist_weighted, &g);
         if (rc) return rc;
         vet::SpatialParams p;
         p.src = src;
@@ -344,7 +353,9 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         p.status = k == 0 ? d_status : nullptr;
         p.FPW = g.FPW; p.G = g.G; p.UC = g.UC;
         p.log2_tab = c->d_log2;
-        if (!pl->weighted && !FROM_IDS && (U & 1) == 0 && U <= 4096 && !p.weights && !getenv("VET_U_NO_LDS")) {
+        p.full_norm = (L.binned && pl->weighted) ? 1 : 0;
+        p.norm_n = L.norm_n;
+        if (!hist_weighted && !FROM_IDS && (U & 1) == 0 && U <= 4096 && !p.weights && !getenv("VET_U_NO_LDS")) {
             // persistent variant with the nearest LUT in LDS: FB frames x U/2 pairs <= 2048 per round
             constexpr int THREADS = 1024;
             int FB = 2048 / (U / 2);
@@ -365,8 +376,8 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
             }
         }
         const int blocks = (T + g.FPW - 1) / g.FPW;
-        const void* fn = pl->weighted ? spatial_w_kernel<FROM_IDS>(weight_mode(pl), g.R)
-                                      : (const void*)vet::k_spatial_u<FROM_IDS>;
+        const void* fn = hist_weighted ? spatial_w_kernel<FROM_IDS>(weight_mode(pl), g.R)
+                                       : (const void*)vet::k_spatial_u<FROM_IDS>;
         void* args[] = {(void*)&p};
         ProfScope ps(c, s, KID_SPATIAL);
         HIP_TRY(hipLaunchKernel(fn, dim3(blocks), dim3(g.NW * vet::WAVE), args, g.lds, s));
@@ -554,7 +565,8 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
         return fail(VET_ERR_INVALID, "FOV angle must be between 0 and 360 degrees");
     if (!(d->power_factor > 0.0)) return fail(VET_ERR_INVALID, "Power factor must be positive");
     for (int k = 0; k < d->n_lattices; ++k) {
-        if (d->n_tiles[k] <= 0 || d->n_tiles[k] > 65535 || !d->h_tiles[k])
+        const bool binned = d->h_bin_lut && d->h_bin_lut[k];
+        if (d->n_tiles[k] <= 0 || d->n_tiles[k] > 65535 || (!binned && !d->h_tiles[k]))
             return fail(VET_ERR_INVALID, "lattice %d: tile count %d outside [1, 65535]", k, d->n_tiles[k]);
     }
     HIP_TRY(hipSetDevice(c->device));
@@ -609,6 +621,19 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
         Lattice& L = pl->lat[k];
         L.n = d->n_tiles[k];
         L.hmax = d->h_max_entropy[k];
+        L.norm_n = d->n_norm_tiles ? d->n_norm_tiles[k] : L.n;
+        if (d->h_bin_lut && d->h_bin_lut[k]) {
+            L.binned = true;
+            for (int64_t i = 0; i < pl->n_dirs; ++i)
+                if (d->h_bin_lut[k][i] >= L.n)
+                    return cleanup(fail(VET_ERR_INVALID, "lattice %d: bin %u of direction %lld >= %d bins", k,
+                                        (unsigned)d->h_bin_lut[k][i], (long long)i, L.n));
+            PLAN_TRY(hipMalloc((void**)&L.d_nearest, (size_t)pl->n_dirs * sizeof(uint16_t)));
+            PLAN_TRY(hipMemcpyAsync(L.d_nearest, d->h_bin_lut[k], (size_t)pl->n_dirs * sizeof(uint16_t),
+                                    hipMemcpyHostToDevice, s));
+            PLAN_TRY(hipStreamSynchronize(s));
+            continue;
+        }
         std::vector<double> unit((size_t)L.n * 3);
         for (int t = 0; t < L.n; ++t) {
             const double x = d->h_tiles[k][3 * t], y = d->h_tiles[k][3 * t + 1], z = d->h_tiles[k][3 * t + 2];

@@ -271,6 +271,9 @@ struct SpatialParams {
     int G;                        // tile groups per frame = ceil(n / (64*R))
     int UC;                       // users per LDS chunk
     const double* log2_tab;       // [4097] log2(k), k = 0..4096 (entry 0 is 0); k_spatial_u_lds only
+    int norm_n;                   // tile count the user count is compared with (= n except binned lattices)
+    int full_norm;                // unweighted kernels: always normalise by log2(n) (binned lattices
+                                  // with use_weight_distribution, entropy_utils.py:442-447)
 };
 
 template <bool FROM_IDS, int WMODE, int R>
@@ -711,7 +714,7 @@ __global__ void k_spatial_u(const SpatialParams p) {
         h = wave_sum(h);
         if (lane == 0) {
             double hmax = p.hmax;                  // entropy_utils.py:201-206
-            if (!(tw > (double)p.n)) {
+            if (!(tw > (double)p.norm_n) && !p.full_norm) {
                 const double mp = 1.0 / tw;
                 hmax = -tw * mp * log2(mp);
             }
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
             h = wave_sum(h);
             if (lane == 0) {
                 double hmax = p.hmax;              // entropy_utils.py:201-206
-                if (!(tw > (double)p.n)) hmax = -tw * (1.0 / tw) * -lgn;      // log2(1/N) = -log2 N
+                if (!(tw > (double)p.norm_n) && !p.full_norm) hmax = -tw * (1.0 / tw) * -lgn;   // log2(1/N) = -log2 N
                 double e = h / hmax;
                 if (np == 0) {
                     e = __builtin_nan("");

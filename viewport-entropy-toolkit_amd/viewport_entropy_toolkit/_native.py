@@ -47,6 +47,7 @@ class _PlanDesc(C.Structure):
         ("h_tiles", C.c_void_p), ("h_max_entropy", C.c_void_p),
         ("fov_angle", C.c_double), ("max_angular_distance", C.c_double),
         ("power_factor", C.c_double), ("use_weight_distribution", C.c_int),
+        ("h_bin_lut", C.c_void_p), ("n_norm_tiles", C.c_void_p),
     ]
 
 
@@ -169,11 +170,19 @@ class Plan:
 
     def __init__(self, engine: Engine, tile_xyz: Sequence[np.ndarray], fov_angle: float, power_factor: float,
                  use_weight_distribution: bool, video_width: int = 0, video_height: int = 0,
-                 dir_table: Optional[np.ndarray] = None):
+                 dir_table: Optional[np.ndarray] = None, bin_luts: Optional[Sequence] = None,
+                 bin_counts: Optional[Sequence[int]] = None, bin_max_entropy: Optional[Sequence[float]] = None,
+                 bin_norm_tiles: Optional[Sequence[int]] = None):
+        """``tile_xyz``: one [n,3] array per lattice.  A *binned* lattice k (naive lat/lon tiling)
+        passes ``tile_xyz[k] = None`` with ``bin_luts[k]`` (uint16 [n_dirs] direction -> bin),
+        ``bin_counts[k]`` bins and the normaliser ``bin_max_entropy[k]``."""
         self.engine = engine
         self.lib = engine.lib
-        self.tiles = [np.ascontiguousarray(t, dtype=np.float64) for t in tile_xyz]
-        self.n_tiles = [len(t) for t in self.tiles]
+        bin_luts = list(bin_luts) if bin_luts is not None else [None] * len(tile_xyz)
+        self.tiles = [np.ascontiguousarray(t, dtype=np.float64) if t is not None else np.zeros((1, 3))
+                      for t in tile_xyz]
+        self.n_tiles = [len(t) if b is None else int(bin_counts[k])
+                        for k, (t, b) in enumerate(zip(self.tiles, bin_luts))]
         self.weighted = bool(use_weight_distribution)
         self.width, self.height = int(video_width), int(video_height)
         d = _PlanDesc()
@@ -189,8 +198,17 @@ class Plan:
             d.h_dir_table, d.n_dirs = tab.ctypes.data, len(tab)
         n_arr = np.asarray(self.n_tiles, dtype=np.int32)
         ptrs = (C.c_void_p * len(self.tiles))(*[t.ctypes.data for t in self.tiles])
-        hmax = np.asarray([_quantiser.max_entropy(n) for n in self.n_tiles], dtype=np.float64)
+        hmax = np.asarray([_quantiser.max_entropy(n) if b is None else float(bin_max_entropy[k])
+                           for k, (n, b) in enumerate(zip(self.n_tiles, bin_luts))], dtype=np.float64)
         keep.extend([n_arr, ptrs, hmax])
+        if any(b is not None for b in bin_luts):
+            luts = [None if b is None else np.ascontiguousarray(b, dtype=np.uint16).reshape(-1) for b in bin_luts]
+            lut_ptrs = (C.c_void_p * len(luts))(*[None if b is None else b.ctypes.data for b in luts])
+            norm = np.asarray([n if b is None else int(bin_norm_tiles[k])
+                               for k, (n, b) in enumerate(zip(self.n_tiles, bin_luts))], dtype=np.int32)
+            keep.extend([luts, lut_ptrs, norm])
+            d.h_bin_lut = C.cast(lut_ptrs, C.c_void_p)
+            d.n_norm_tiles = norm.ctypes.data
         d.n_lattices = len(self.tiles)
         d.n_tiles = n_arr.ctypes.data
         d.h_tiles = C.cast(ptrs, C.c_void_p)

@@ -2,5 +2,6 @@
 
 from .spatial_entropy import SpatialEntropyAnalyzer
 from .transition_entropy import TransitionEntropyAnalyzer
+from .naive_spatial_entropy import NaiveSpatialEntropyAnalyzer
 
-__all__ = ["SpatialEntropyAnalyzer", "TransitionEntropyAnalyzer"]
+__all__ = ["SpatialEntropyAnalyzer", "TransitionEntropyAnalyzer", "NaiveSpatialEntropyAnalyzer"]

@@ -42,3 +42,28 @@ class AnalyzerConfig:
 
     def get_output_path(self, base_name: str, extension: str) -> Path:
         return self.output_dir / f"{base_name}{extension}"
+
+
+@dataclass
+class NaiveAnalyzerConfig:
+    """Configuration of the latitude-longitude grid analyzer (reference config.py:84-126):
+    ``tile_height`` must divide 180 and ``tile_width`` 360 (degrees)."""
+
+    video_width: int = DEFAULT_VIDEO_DIMENSIONS["width"]
+    video_height: int = DEFAULT_VIDEO_DIMENSIONS["height"]
+    output_dir: Path = Path("output")
+    entropy_config: EntropyConfig = field(default_factory=EntropyConfig)
+    visualization_config: VisualizationConfig = field(default_factory=VisualizationConfig)
+    tile_width: int = -1
+    tile_height: int = -1
+
+    def __post_init__(self) -> None:
+        if self.video_width <= 0 or self.video_height <= 0:
+            raise ValueError("Video dimensions must be positive")
+        if not self.tile_height or not self.tile_width:
+            raise ValueError("Must specify both tile_height and tile_width")
+        self.output_dir = Path(self.output_dir)
+        self.output_dir.mkdir(parents=True, exist_ok=True)
+
+    def get_output_path(self, base_name: str, extension: str) -> Path:
+        return self.output_dir / f"{base_name}{extension}"

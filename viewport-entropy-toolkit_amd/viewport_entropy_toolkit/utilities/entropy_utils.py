@@ -13,7 +13,7 @@ from typing import Dict, List, Tuple
 
 import numpy as np
 
-from ..data_types import Vector, ValidationError
+from ..data_types import RadialPoint, Vector, ValidationError
 from .. import _native
 
 
@@ -116,3 +116,54 @@ def compute_transition_entropy(prior_vector_dict: dict, current_vector_dict: dic
     weights = {tile_centers[int(i)]: int(src[i]) for i in np.nonzero(src > 0)[0]}
     assignments = {k: (int(p), int(c)) for k, (p, c) in zip(users, res["pairs"][0])}
     return float(res["entropy"][0]), weights, assignments
+
+
+# --------------------------------------------------------------------------------------------
+# naive latitude-longitude grid tiling (reference utilities/entropy_utils.py:335-452)
+# --------------------------------------------------------------------------------------------
+def find_naive_tile_index(point: RadialPoint, tile_height: float, tile_width: float) -> str:
+    """``"{lon index}_{lat index}"`` of the grid cell the point sits in (truncating division)."""
+    return f"{int((point.lon + 180) / tile_width)}_{int((point.lat + 90) / tile_height)}"
+
+
+def calculate_naive_tile_weights(point: RadialPoint, tile_height: float, tile_width: float,
+                                 config: EntropyConfig) -> Dict[str, float]:
+    """The whole weight 1.0 goes to the point's own grid cell."""
+    return {find_naive_tile_index(point, tile_height, tile_width): 1.0}
+
+
+def naive_tile_count(tile_height, tile_width) -> int:
+    return int(180.0 / tile_height) * int(360.0 / tile_width)
+
+
+def compute_naive_spatial_entropy(points_dict: Dict[str, RadialPoint], tile_height: int, tile_width: int,
+                                  config: EntropyConfig) -> Tuple[float, Dict[str, float], Dict[str, str]]:
+    """Normalised Shannon entropy of one frame's users over the lat/lon grid cells.
+
+    Returns (entropy, {cell key: user count}, {identifier: cell key}).  The cell index arithmetic
+    is the quantiser and runs on the host; the histogram and entropy run on the HIP engine."""
+    if not points_dict:
+        raise ValidationError("Empty radial points dictionary")
+    if not tile_height or not tile_width:
+        raise ValidationError("No tile dimensions provided")
+    if 180 % tile_height != 0:
+        raise ValidationError("Tile height must divide 180!")
+    if 360 % tile_width != 0:
+        raise ValidationError("Tile width must divide 360!")
+    users = [(k, find_naive_tile_index(p, tile_height, tile_width)) for k, p in points_dict.items() if p is not None]
+    if not users:
+        raise ZeroDivisionError("float division by zero")
+    cells = sorted({c for _, c in users})
+    cell_id = {c: i for i, c in enumerate(cells)}
+    num_tiles = naive_tile_count(tile_height, tile_width)
+    plan = _native.Plan(_native.Engine.default(), [None], config.fov_angle, config.power_factor,
+                        config.use_weight_distribution, dir_table=np.tile([1.0, 0.0, 0.0], (len(users), 1)),
+                        bin_luts=[np.array([cell_id[c] for _, c in users], dtype=np.uint16)],
+                        bin_counts=[len(cells)], bin_max_entropy=[_native._quantiser.max_entropy(num_tiles)],
+                        bin_norm_tiles=[num_tiles])
+    try:
+        res = plan.spatial(ids=np.arange(len(users), dtype=np.int32)[None, :], want_assign=False, want_weights=True)
+    finally:
+        plan.close()
+    weights = {c: float(res["weights"][0][i]) for c, i in cell_id.items()}
+    return float(res["entropy"][0]), weights, {k: c for k, c in users}
