@@ -88,7 +88,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    multi = world > 1
+    multi = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ     # under torch.distributed.run: RCCL path
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if multi:
