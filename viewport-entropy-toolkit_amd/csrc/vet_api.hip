@@ -236,12 +236,15 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(d_max);
     if (e != hipSuccess) return fail(VET_ERR_DEVICE, "k_wtab<count> failed: %s", hipGetErrorString(e));
-    int stride = ((longest > 0 ? longest : 1) + 15) & ~15;
+    int align = 64;      // rows start on 128-byte lines (u16 tile rows) / 256 bytes (u32 weight rows)
+    if (const char* e = getenv("VET_STRIDE_ALIGN")) align = atoi(e);
+    int stride = ((longest > 0 ? longest : 1) + align - 1) / align * align;
     const size_t bytes = (size_t)pl->n_dirs * stride * 6;
     if (bytes > kMaxTableBytes) { L.stride = -1; return VET_OK; }
-    HIP_TRY(hipMalloc((void**)&L.d_tab_w, (size_t)pl->n_dirs * stride * 4));
-    HIP_TRY(hipMalloc((void**)&L.d_tab_i, (size_t)pl->n_dirs * stride * 2));
-    HIP_TRY(hipMalloc((void**)&L.d_tab_len, (size_t)pl->n_dirs * 2));
+    // one extra, all-zero row (index n_dirs) for the gather's idle lanes
+    HIP_TRY(hipMalloc((void**)&L.d_tab_w, (size_t)(pl->n_dirs + 1) * stride * 4));
+    HIP_TRY(hipMalloc((void**)&L.d_tab_i, (size_t)(pl->n_dirs + 1) * stride * 2));
+    HIP_TRY(hipMalloc((void**)&L.d_tab_len, (size_t)(pl->n_dirs + 1) * 2));
     p.stride = stride; p.w = L.d_tab_w; p.idx = L.d_tab_i; p.len = L.d_tab_len; p.maxcount = nullptr;
     {
         ProfScope ps(c, s, KID_WTAB);
@@ -302,7 +305,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
             int fpw = U >= 256 ? 1 : (U >= 64 ? 4 : 16);
             size_t lds = 0;
             for (;; fpw /= 2) {
-                lds = (size_t)fpw * q.n_sum * 8 + (size_t)fpw * q.UC * 4 + (size_t)2 * fpw * 4 + 64;
+                lds = (size_t)fpw * q.n_sum * 8 + (size_t)fpw * q.UC * 6 + (size_t)2 * fpw * 4 + 64;
                 if (lds <= c->lds_max || fpw == 1) break;
             }
             if (lds <= c->lds_max) {

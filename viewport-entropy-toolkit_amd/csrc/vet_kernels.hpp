@@ -440,15 +440,24 @@ __global__ void k_wtab(const WtabParams p) {
             count += __popcll(mask);
         }
         if (FILL) {
+            // padding: weight 0 on distinct tiles, so the gather can add every slot unconditionally
+            // without piling zero adds onto one LDS address
             for (int pos = count + lane; pos < p.stride; pos += WAVE) {
                 p.w[d * p.stride + pos] = 0u;
-                p.idx[d * p.stride + pos] = 0;
+                p.idx[d * p.stride + pos] = (uint16_t)(pos % p.n);
             }
             if (lane == 0) p.len[d] = (uint16_t)count;
         }
         longest = max(longest, count);
     }
     if (!FILL && lane == 0 && longest > 0) atomicMax(p.maxcount, longest);
+    if (FILL && wave == 0) {            // row D: the all-zero row idle lanes of the gather point at
+        for (int pos = lane; pos < p.stride; pos += WAVE) {
+            p.w[p.D * p.stride + pos] = 0u;
+            p.idx[p.D * p.stride + pos] = (uint16_t)(pos % p.n);
+        }
+        if (lane == 0) p.len[p.D] = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -458,43 +467,46 @@ __global__ void k_wtab(const WtabParams p) {
 // group walks to the longest of its UN rows only.
 // ------------------------------------------------------------------------------------------
 template <int UN>
-__device__ __forceinline__ void walk_rows(const int* fids, int nu, unsigned long long* hrow,
+__device__ __forceinline__ void walk_rows(const int* fids, const uint16_t* flens, int nu, unsigned long long* hrow,
                                           const uint32_t* __restrict__ tab_w, const uint16_t* __restrict__ tab_i,
-                                          const uint16_t* __restrict__ tab_len, int stride, int gs_log2) {
-    // every lane takes 4 consecutive entries: one 16-byte load of weights, one 8-byte load of tiles
-    // (stride is a multiple of 16 entries, so rows are 64 / 32 byte aligned)
+                                          int stride, int gs_log2, long zero_row) {
+    // Every lane takes 4 consecutive entries: one 16-byte load of weights, one 8-byte load of tiles
+    // (stride is a multiple of 16 entries, so rows are 64 / 32 byte aligned), then four
+    // unconditional ds_add_u64: padding slots and idle lanes (which walk the all-zero row) add 0
+    // to distinct tiles.  The kernel is instruction-issue bound, so no predicates in this loop.
     const int NW = blockDim.x >> 6, lane = lane_id(), wv = wave_id();
     const int GS = 1 << gs_log2, UPW = WAVE >> gs_log2;
     const int sub = lane >> gs_log2, sl = lane & (GS - 1);
     const int step = NW * UPW;
     for (int j0 = wv * UPW; j0 < nu; j0 += UN * step) {
         long row[UN];
-        bool on[UN];
+        int len[UN];
         int longest = 0;
 #pragma unroll
         for (int k = 0; k < UN; ++k) {
             const int j = j0 + k * step + sub;
-            on[k] = j < nu;
-            const int id = on[k] ? fids[j] : 0;
-            row[k] = (long)id * stride;
-            longest = max(longest, on[k] ? (int)tab_len[id] : 0);
+            const bool on = j < nu;
+            row[k] = on ? (long)fids[j] * stride : zero_row;
+            len[k] = on ? (int)flens[j] : 0;
+            longest = max(longest, len[k]);
         }
         for (int e = 4 * sl; e < longest; e += 4 * GS) {
             uint4 w[UN];
             ushort4 t[UN];
+            // a row that has ended reads the all-zero row (same slots, one hot line) instead of
+            // its own padding lines: the gather is bound by cache lines touched (TA/TD busy)
 #pragma unroll
             for (int k = 0; k < UN; ++k) {
-                w[k] = *(const uint4*)(tab_w + row[k] + e);
-                t[k] = *(const ushort4*)(tab_i + row[k] + e);
+                const long r = e < len[k] ? row[k] : zero_row;
+                w[k] = *(const uint4*)(tab_w + r + e);
+                t[k] = *(const ushort4*)(tab_i + r + e);
             }
 #pragma unroll
             for (int k = 0; k < UN; ++k) {
-                if (on[k]) {
-                    if (w[k].x) atomicAdd(&hrow[t[k].x], (unsigned long long)w[k].x);
-                    if (w[k].y) atomicAdd(&hrow[t[k].y], (unsigned long long)w[k].y);
-                    if (w[k].z) atomicAdd(&hrow[t[k].z], (unsigned long long)w[k].z);
-                    if (w[k].w) atomicAdd(&hrow[t[k].w], (unsigned long long)w[k].w);
-                }
+                atomicAdd(&hrow[t[k].x], (unsigned long long)w[k].x);
+                atomicAdd(&hrow[t[k].y], (unsigned long long)w[k].y);
+                atomicAdd(&hrow[t[k].z], (unsigned long long)w[k].z);
+                atomicAdd(&hrow[t[k].w], (unsigned long long)w[k].w);
             }
         }
     }
@@ -505,6 +517,7 @@ __device__ __forceinline__ void walk_rows(const int* fids, int nu, unsigned long
 // the direction weight table.  FPW frames per workgroup.
 // LDS:  hist u64 [FPW][n]   per-frame tile weight sums (units of 2^-32)
 //       ids  i32 [FPW][UC]  direction ids of the present users (compacted)
+//       lens u16 [FPW][UC]  their row lengths in the lattice being gathered
 //       cnt  i32 [FPW] chunk-present, [FPW] frame-present
 // A group of GS = 2^gs_log2 lanes walks one user's row (coalesced u32 + u16 loads) and adds the
 // non-zero entries into the frame histogram with ds_add_u64; a wave serves 64/GS users at once
@@ -545,6 +558,7 @@ __global__ void k_spatial_lut(const LutParams p) {
     int* ids = (int*)(hist + (size_t)p.FPW * p.n_sum);                           // [FPW][UC]
     int* cnt_chunk = ids + (size_t)p.FPW * p.UC;                                 // [FPW]
     int* cnt_frame = cnt_chunk + p.FPW;                                          // [FPW]
+    uint16_t* lens = (uint16_t*)(cnt_frame + p.FPW);                             // [FPW][UC] row lengths
     const int NW = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const long f0 = (long)blockIdx.x * p.FPW;
@@ -566,14 +580,22 @@ __global__ void k_spatial_lut(const LutParams p) {
         }
         __syncthreads();
         for (int i = tid; i < p.FPW; i += blockDim.x) cnt_frame[i] += cnt_chunk[i];
-        for (int fl = 0; fl < nf; ++fl) {
-            unsigned long long* hrow = hist + (size_t)fl * p.n_sum;
-            for (int k = 0; k < p.K; ++k) {
-                const LutLattice& L = p.lat[k];
-                walk_rows<UN>(ids + (size_t)fl * p.UC, cnt_chunk[fl], hrow, L.tab_w, L.tab_i, L.tab_len, L.stride,
-                              L.gs_log2);
-                hrow += L.n;
+        int hoff = 0;
+        for (int k = 0; k < p.K; ++k) {
+            const LutLattice& L = p.lat[k];
+            // row lengths of this lattice for every staged user: one parallel gather, so the walk
+            // below has no dependent global load in front of its row loads
+            if (k) __syncthreads();
+            for (int i = tid; i < nf * p.UC; i += blockDim.x) {
+                const int fl = i / p.UC, j = i - fl * p.UC;
+                if (j < cnt_chunk[fl]) lens[i] = L.tab_len[ids[i]];
             }
+            __syncthreads();
+            for (int fl = 0; fl < nf; ++fl)
+                walk_rows<UN>(ids + (size_t)fl * p.UC, lens + (size_t)fl * p.UC, cnt_chunk[fl],
+                              hist + (size_t)fl * p.n_sum + hoff, L.tab_w, L.tab_i, L.stride, L.gs_log2,
+                              (long)p.src.n_dirs * L.stride);
+            hoff += L.n;
         }
     }
     __syncthreads();
