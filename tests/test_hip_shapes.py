@@ -117,3 +117,16 @@ def test_heavily_clustered_users(native, engine):
     assert np.array_equal(tr["pairs"], pairs)
     np.testing.assert_allclose(tr["entropy"], ent, rtol=1e-9)
     plan.close()
+
+
+def test_table_formulation_on_a_larger_grid(native, engine):
+    """640x480 pixels: 308 k directions; a 400 k-sample video makes the auto policy pick the
+    direction weight table (118 MB)."""
+    mu, mv = video(1000, 400, seed=99, p_absent=0.02)
+    plan = plan_for(native, engine, [50], 640, 480)
+    res = plan.spatial(mu=mu, mv=mv)
+    assert plan.table_stride(0) > 0
+    ent, assign, _ = vo.spatial_series(mu, mv, 640, 480, [50])
+    assert np.array_equal(res["assign"], assign)
+    np.testing.assert_allclose(res["entropy"], ent, rtol=1e-8)
+    plan.close()
