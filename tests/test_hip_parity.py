@@ -339,3 +339,18 @@ def test_config5_transition_full_size_properties(native, engine):
         e = vo.transition_entropy_pairs(tile[r], tile[r + 1], 201)
         np.testing.assert_allclose(a["entropy"][r], e, rtol=RTOL)
     plan.close()
+
+
+def test_auto_policy_builds_tables_once_a_plan_has_seen_enough_samples(native, engine):
+    """Small videos sweep; a plan reused for many of them switches to the table (same results)."""
+    from viewport_entropy_toolkit import _synthetic
+    plan = make_plan(native, engine, [50, 100], policy=0)
+    outs = []
+    for v in range(12):                                   # 12 x 2400 samples > 20 301 directions
+        mu, mv = _synthetic.random_walk_video(8, 300, base_seed=5, video_id=v)
+        outs.append((mu, mv, plan.spatial(mu=mu, mv=mv)["entropy"], plan.table_stride(0) > 0))
+    assert not outs[0][3] and outs[-1][3]
+    for mu, mv, ent, _ in (outs[0], outs[-1]):
+        ref, _, _ = vo.spatial_series(mu, mv, 100, 200, [50, 100])
+        np.testing.assert_allclose(ent, ref, rtol=1e-8)
+    plan.close()

@@ -93,6 +93,8 @@ struct vet_plan {
     int weighted = 1;
     double cos_cull = 0.0;
     int table_policy = 0;          // 0 auto, 1 always use the weight table, -1 never
+    long samples_seen = 0;         // samples this plan has processed (auto policy: tables pay off
+                                   // once a plan has seen as many samples as it has directions)
 };
 
 namespace {
@@ -263,7 +265,10 @@ bool any_binned(const vet_plan* pl) {
 bool want_table(const vet_plan* pl, int U, int T) {
     if (!pl->weighted || pl->table_policy < 0 || any_binned(pl)) return false;
     if (pl->table_policy > 0) return true;
-    return (long)U * T >= (long)pl->n_dirs;      // rows are reused on average at least once
+    // rows are reused on average at least once over the plan's lifetime (an analyzer usually
+    // serves many videos), or the tables exist already
+    if (pl->lat[0].stride > 0) return true;
+    return pl->samples_seen + (long)U * T >= (long)pl->n_dirs;
 }
 
 template <bool FROM_IDS>
@@ -274,6 +279,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
     double* ent_k = d_entropy;
     int ubits = 0;
     while ((1L << ubits) < (long)U) ++ubits;
+    struct Seen { vet_plan* p; long n; ~Seen() { p->samples_seen += n; } } seen{pl, (long)U * T};
     // ---- weighted, table formulation: every lattice in one launch
     if (want_table(pl, U, T) && K <= vet::MAX_LATTICES) {
         bool ok = true;
