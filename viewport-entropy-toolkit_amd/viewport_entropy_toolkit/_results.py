@@ -15,10 +15,23 @@ import numpy as np
 
 
 class _RowView(Mapping):
-    __slots__ = ("_keys", "_row", "_present")
+    """Base of the per-frame views: holds references only; everything else is computed on access
+    (a 30 000-frame result builds 60 000 of these, so construction must stay trivial)."""
+
+    __slots__ = ("_keys", "_row")
+
+    def __init__(self, keys, row):
+        self._keys = keys
+        self._row = row
+
+    def _mask(self):
+        raise NotImplementedError
+
+    def _value(self, i):
+        raise NotImplementedError
 
     def _items(self):
-        raise NotImplementedError
+        return ((self._keys[int(i)], self._value(i)) for i in np.nonzero(self._mask())[0])
 
     def _materialise(self) -> dict:
         return dict(self._items())
@@ -30,42 +43,48 @@ class _RowView(Mapping):
         return (k for k, _ in self._items())
 
     def __len__(self):
-        return int(np.count_nonzero(self._present))
+        return int(np.count_nonzero(self._mask()))
 
     def __repr__(self):
         return repr(self._materialise())
 
 
 class TileWeights(_RowView):
-    """{tile Vector: weight} for the tiles a frame touched."""
-
-    def __init__(self, tiles: Sequence, row: np.ndarray, as_int: bool = False):
-        self._keys, self._row, self._present = tiles, row, row > 0
-        self._as_int = as_int
+    """{tile Vector: weight} for the tiles a frame touched (float sums, or int counts)."""
 
     __slots__ = ("_as_int",)
 
-    def _items(self):
-        cast = int if self._as_int else float
-        return ((self._keys[int(i)], cast(self._row[i])) for i in np.nonzero(self._present)[0])
+    def __init__(self, tiles: Sequence, row: np.ndarray, as_int: bool = False):
+        self._keys = tiles
+        self._row = row
+        self._as_int = as_int
+
+    def _mask(self):
+        return self._row > 0
+
+    def _value(self, i):
+        return int(self._row[i]) if self._as_int else float(self._row[i])
 
 
 class TileAssignments(_RowView):
     """{user identifier: nearest tile index} for the users present in a frame."""
 
-    def __init__(self, users: List[str], row: np.ndarray):
-        self._keys, self._row, self._present = users, row, row >= 0
+    __slots__ = ()
 
-    def _items(self):
-        return ((self._keys[int(i)], int(self._row[i])) for i in np.nonzero(self._present)[0])
+    def _mask(self):
+        return self._row >= 0
+
+    def _value(self, i):
+        return int(self._row[i])
 
 
 class TilePairs(_RowView):
     """{user identifier: (prior tile index, current tile index)} for users in both frames."""
 
-    def __init__(self, users: List[str], row: np.ndarray):
-        self._keys, self._row, self._present = users, row, row[:, 0] >= 0
+    __slots__ = ()
 
-    def _items(self):
-        return ((self._keys[int(i)], (int(self._row[i, 0]), int(self._row[i, 1])))
-                for i in np.nonzero(self._present)[0])
+    def _mask(self):
+        return self._row[:, 0] >= 0
+
+    def _value(self, i):
+        return (int(self._row[i, 0]), int(self._row[i, 1]))
