@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/pmc.sh <workload> <tag>   — SQ/TCC counter passes for the dominant kernel
+# usage: tools/pmc.sh <workload> <tag>   — SQ/TCC counter passes for the dominant kernel
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 W=$1; TAG=$2
@@ -9,4 +9,4 @@ rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/$TAG/fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload $W > gpurun_out/$TAG/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/$TAG/write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload $W > gpurun_out/$TAG/write.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --workload $W > gpurun_out/$TAG/trace.log 2>&1
-python3 scratch/pmc_summary.py gpurun_out/$TAG
+python3 tools/pmc_summary.py gpurun_out/$TAG

@@ -9,4 +9,4 @@ run SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK
 run TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum
 run TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run TA_BUSY_avr TA_TA_BUSY_sum TD_TD_BUSY_sum
-python3 scratch/pmc_summary.py gpurun_out/$TAG
+python3 tools/pmc_summary.py gpurun_out/$TAG

@@ -757,7 +757,7 @@ __global__ void k_spatial_u(const SpatialParams p) {
 
 // ------------------------------------------------------------------------------------------
 // k_spatial_u_lds — k_spatial_u for plans whose nearest-tile LUT fits the LDS (40 KB at the
-// default 100x200 grid).  Measured on MI355X (scratch/stream_probe.hip): the 2-byte LUT gather
+// default 100x200 grid).  Measured on MI355X (tools/stream_probe.hip): the 2-byte LUT gather
 // from global memory runs at about one lane per cycle per CU and costs 70 us of a 177 us
 // kernel, while the same stream with the LUT in LDS reaches 5.1 TB/s.  So: persistent
 // workgroups (1024 threads, 2 per CU) load the LUT into LDS once and walk the frame axis in
