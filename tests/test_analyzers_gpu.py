@@ -220,3 +220,15 @@ def test_naive_config3_size_vs_oracle():
         ent = an.compute_entropy()["entropy"].to_numpy()
         ref, _, _ = vo.naive_series(mu, mv, 100, 200, 10, 20, flag)
         np.testing.assert_allclose(ent, ref, rtol=1e-9)
+
+
+def test_analyze_directories_single_process(tmp_path, golden_dir):
+    """The multi-GPU driver degenerates to a plain loop without a process group."""
+    from viewport_entropy_toolkit import _dist
+    g = _write_config1(golden_dir, tmp_path / "v0")
+    _write_config1(golden_dir, tmp_path / "v1")
+    cfg = AnalyzerConfig(tile_counts=[50], output_dir=tmp_path / "out")
+    got = _dist.analyze_directories([tmp_path / "v0", tmp_path / "v1"], cfg)
+    assert sorted(got) == [0, 1]
+    for v in got.values():
+        np.testing.assert_allclose(v, g["w_tc50__entropy"], rtol=RTOL)

@@ -114,3 +114,20 @@ def transition_frame_sharded(mu: np.ndarray, mv: np.ndarray, compute: Callable[[
     base, extra = divmod(max(T - 1, 0), world)
     got = gather_series(part, dst=dst, max_len=base + (1 if extra else 0), device=device)
     return np.concatenate(got) if got is not None else None
+
+
+def analyze_directories(directories: Sequence, config=None, mode: str = "spatial", dst: int = 0, device=None):
+    """One video directory per GPU at a time (README.md:108-120 of the reference suggests a process
+    pool; here it is one process per GPU under ``torch.distributed.run``).  Every rank builds its own
+    analyzer, runs ``process_directory`` + ``compute_entropy`` on its share and contributes the
+    entropy series to ONE gather per round.  Returns ``{directory index: entropy[T]}`` on ``dst``."""
+    from . import SpatialEntropyAnalyzer, TransitionEntropyAnalyzer
+
+    cls = {"spatial": SpatialEntropyAnalyzer, "transition": TransitionEntropyAnalyzer}[mode]
+    analyzer = cls(config)
+
+    def compute(directory):
+        analyzer.process_directory(directory)
+        return analyzer.compute_entropy()["entropy"].to_numpy(dtype=np.float64)
+
+    return analyze_videos(list(directories), compute, dst=dst, device=device)
