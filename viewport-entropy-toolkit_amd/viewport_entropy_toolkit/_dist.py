@@ -58,7 +58,12 @@ def gather_series(series: np.ndarray, dst: int = 0, max_len: Optional[int] = Non
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return [series.copy()]
     world, rank = dist.get_world_size(), dist.get_rank()
-    dev = device if device is not None else torch.device("cpu")
+    if device is not None:
+        dev = device
+    elif dist.get_backend() == "nccl":           # RCCL moves device buffers
+        dev = torch.device("cuda", torch.cuda.current_device())
+    else:
+        dev = torch.device("cpu")
     if max_len is None:
         m = torch.tensor([len(series)], dtype=torch.int64, device=dev)
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
