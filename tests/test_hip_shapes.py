@@ -130,3 +130,22 @@ def test_table_formulation_on_a_larger_grid(native, engine):
     assert np.array_equal(res["assign"], assign)
     np.testing.assert_allclose(res["entropy"], ent, rtol=1e-8)
     plan.close()
+
+
+@pytest.mark.parametrize("fov,power", [(180.0, 2.0), (360.0, 1.0), (0.5, 2.0), (120.0, 50.0), (120.0, 0.01),
+                                       (119.999, 2.0), (120.001, 2.0), (60.0, 1.0), (300.0, 0.3)])
+@pytest.mark.parametrize("policy", [-1, 1])
+def test_extreme_entropy_configs(native, engine, fov, power, policy):
+    """Cone edges (fov 180 / 360 / sub-degree), the fast-acos boundary at 120 degrees, and very
+    large / small power factors, in both weighted formulations."""
+    mu, mv = video(60, 40, seed=int(fov * 10 + power))
+    plan = plan_for(native, engine, [100, 20], policy=policy, fov=fov, power=power)
+    res = plan.spatial(mu=mu, mv=mv, want_weights=True)
+    ent, assign, weights = vo.spatial_series(mu, mv, 100, 200, [100, 20], fov_angle=fov, power_factor=power,
+                                             want_weights=True)
+    assert np.array_equal(res["assign"], assign)
+    # the table stores w * 2^32 (saturating at 1 - 2^-32): 2^-32 absolute per weight
+    np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=2.0 ** -32 * 60 + 1e-12)
+    ok = np.isfinite(ent)
+    np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=2e-7 if power > 10 else 1e-8, atol=1e-12)
+    plan.close()
