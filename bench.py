@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", default="videos", choices=["videos", "frames"],
+                    help="N > 1: one video per GPU (weak scaling, default) or ONE video cut along the frame "
+                         "axis with a 1-frame halo in transition mode (strong scaling, BASELINE config 5)")
     args = ap.parse_args()
 
     import torch
@@ -98,7 +101,20 @@ def main():
     from viewport_entropy_toolkit import _native, _quantiser
 
     U, T, tcs, mode, weighted = WORKLOADS[args.workload]
-    mu_h, mv_h = synth_video(U, T, args.seed, rank)
+    T_total = T
+    strong = args.shard == "frames" and world > 1
+    if strong:
+        # every rank synthesises the same video and keeps its block of rows (+ halo frame)
+        from viewport_entropy_toolkit import _dist
+        mu_h, mv_h = synth_video(U, T, args.seed, 0)
+        if mode == "transition":
+            r0, r1, f0, f1 = _dist.transition_frame_block(T, rank, world)
+        else:
+            f0, f1 = _dist.frame_shard(T, rank, world)
+        mu_h, mv_h = np.ascontiguousarray(mu_h[f0:f1]), np.ascontiguousarray(mv_h[f0:f1])
+        T = f1 - f0
+    else:
+        mu_h, mv_h = synth_video(U, T, args.seed, rank)
     mu = torch.from_numpy(mu_h).to(dev)
     mv = torch.from_numpy(mv_h).to(dev)
     R = T if mode == "spatial" else T - 1
@@ -106,7 +122,10 @@ def main():
     # nearest-tile output of lattice 0: [T,U] int32 (spatial) / [(T-1),U,2] int32 (transition)
     idx = torch.empty((T, U) if mode == "spatial" else (R, U, 2), dtype=torch.int32, device=dev)
     status = torch.zeros(2, dtype=torch.int32, device=dev)
-    gathered = [torch.empty(R, dtype=torch.float64, device=dev) for _ in range(world)] if (multi and rank == 0) else None
+    # frame shards differ by at most one row: gather buffers of the largest shard
+    Rg = R if not strong else (T_total - (1 if mode == "transition" else 0) + world - 1) // world
+    send = ent if Rg == R else torch.zeros(Rg, dtype=torch.float64, device=dev)
+    gathered = [torch.empty(Rg, dtype=torch.float64, device=dev) for _ in range(world)] if (multi and rank == 0) else None
 
     eng = _native.Engine(local_rank)
     t0 = time.perf_counter()
@@ -123,7 +142,9 @@ def main():
             plan.transition_device(mu.data_ptr(), mv.data_ptr(), U, T, ent.data_ptr(), d_pairs=idx.data_ptr(),
                                    d_status=status.data_ptr(), stream=stream)
         if multi:
-            dist.gather(ent, gathered, dst=0)
+            if send is not ent:
+                send[:R].copy_(ent)
+            dist.gather(send, gathered, dst=0)
 
     def fence():
         if multi:
@@ -163,7 +184,7 @@ def main():
     assert np.isfinite(e_host).all()
 
     if rank == 0:
-        samples_per_step = U * T * world
+        samples_per_step = U * T_total if strong else U * T * world
         ms_per_step = elapsed / args.steps * 1e3
         # algorithmic bytes: 16 B in + 4 B (8 B transition) out per sample and 8 B of
         # entropy per frame, the samples counted once whatever the number of lattices; per launch of
@@ -184,13 +205,14 @@ def main():
         out = {
             "metric": "viewport samples/sec", "value": samples_per_step / (ms_per_step * 1e-3), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {world} video(s) x {U} users x {T} frames, "
                                    f"tile_counts={tcs}, {mode}, "
                                    f"use_weight_distribution={weighted}, fov=120, W=100, H=200",
                        "users": U, "frames": T, "tile_counts": tcs, "mode": mode,
-                       "videos_per_gpu": 1, "parallelism": f"one video per GPU x{world}"},
-            "frames_per_s": R * world / (ms_per_step * 1e-3),
+                       "videos_per_gpu": 1, "parallelism": (f"one video cut into {world} frame blocks" if strong
+                                       else f"one video per GPU x{world}")},
+            "frames_per_s": (T_total if strong else R * world) / (ms_per_step * 1e-3),
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes_launch,
