@@ -149,3 +149,32 @@ def test_extreme_entropy_configs(native, engine, fov, power, policy):
     ok = np.isfinite(ent)
     np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=2e-7 if power > 10 else 1e-8, atol=1e-12)
     plan.close()
+
+
+def test_cabi_argument_validation(native, engine):
+    """Bad arguments come back as VET_ERR_INVALID / UNSUPPORTED with a message, not as a crash."""
+    import ctypes as C
+    lib = native.load_library()
+    L = vo.fibonacci_lattice(20)
+    with pytest.raises(native.NativeError) as ei:
+        native.Plan(engine, [L], 0.0, 2.0, True, 100, 200)              # fov outside (0, 360]
+    assert ei.value.code == native.VET_ERR_INVALID and "FOV" in str(ei.value)
+    with pytest.raises(native.NativeError):
+        native.Plan(engine, [L], 120.0, -1.0, True, 100, 200)           # power <= 0
+    with pytest.raises(native.NativeError):
+        native.Plan(engine, [np.zeros((4, 3))], 120.0, 2.0, True, 100, 200)   # zero-length tile vector
+    plan = native.Plan(engine, [L], 120.0, 2.0, True, 100, 200)
+    assert lib.vet_spatial_entropy(plan.handle, None, None, 4, 4, None, None, None, None, None, None) == native.VET_ERR_INVALID
+    assert b"NULL" in lib.vet_last_error()
+    assert lib.vet_spatial_entropy_host(plan.handle, None, None, None, 4, 4, None, None, None, None) == native.VET_ERR_INVALID
+    e = np.empty(4)
+    assert lib.vet_spatial_entropy_host(plan.handle, None, None, None, 0, 4, e.ctypes.data_as(C.c_void_p), None, None, None) == native.VET_ERR_INVALID
+    # ids beyond the direction table are flagged like out-of-range samples
+    res = plan.spatial(ids=np.array([[0, 5, 10 ** 7]], dtype=np.int32), check=False)
+    assert res["code"] == native.VET_ERR_RANGE
+    # transition with more users than the LDS hash can hold is refused, not wrong
+    big = np.full((2, 9000), 0.5)
+    with pytest.raises(native.NativeError) as ei:
+        plan.transition(mu=big, mv=big)
+    assert ei.value.code == native.VET_ERR_UNSUPPORTED
+    plan.close()
