@@ -178,3 +178,40 @@ def test_cabi_argument_validation(native, engine):
         plan.transition(mu=big, mv=big)
     assert ei.value.code == native.VET_ERR_UNSUPPORTED
     plan.close()
+
+
+@pytest.mark.parametrize("policy", [-1, 1])
+def test_very_large_lattice(native, engine, policy):
+    """tile_count = 5000 (5001 tiles): more tile groups than waves in the sweep, long table rows."""
+    mu, mv = video(50, 12, seed=5)
+    plan = plan_for(native, engine, [5000], policy=policy)
+    res = plan.spatial(mu=mu, mv=mv, want_weights=True)
+    ent, assign, weights = vo.spatial_series(mu, mv, 100, 200, [5000], want_weights=True)
+    assert np.array_equal(res["assign"], assign)
+    np.testing.assert_allclose(res["entropy"], ent, rtol=1e-8)
+    np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=2.0 ** -32 * 50 + 1e-12)
+    tr = plan.transition(mu=mu, mv=mv)
+    e2, pairs = vo.transition_series(mu, mv, 100, 200, [5000])
+    assert np.array_equal(tr["pairs"], pairs)
+    np.testing.assert_allclose(tr["entropy"], e2, rtol=1e-9, equal_nan=True)
+    plan.close()
+
+
+@pytest.mark.parametrize("policy", [-1, 1])
+def test_ids_with_several_lattices(native, engine, policy):
+    rng = np.random.default_rng(12)
+    table = vo.vector_from_spherical(np.round(rng.uniform(-180, 180, 500), 1), np.round(rng.uniform(-90, 90, 500), 1))
+    ids = rng.integers(0, 500, (30, 70)).astype(np.int32)
+    ids[rng.random(ids.shape) < 0.2] = -1
+    ids[:, 3] = 7
+    tcs = [100, 20, 250]
+    plan = native.Plan(engine, [vo.fibonacci_lattice(tc) for tc in tcs], 120.0, 2.0, True, dir_table=table)
+    plan.set_table_policy(policy)
+    res = plan.spatial(ids=ids)
+    ref = np.zeros(len(ids))
+    for tc in tcs:
+        L = vo.fibonacci_lattice(tc)
+        ref += np.array([vo.spatial_entropy_frame(table[r[r >= 0]], L)[0] for r in ids])
+    np.testing.assert_allclose(res["entropy"], ref / len(tcs), rtol=1e-8)
+    assert np.array_equal(res["present"], (ids >= 0).sum(1))
+    plan.close()
