@@ -40,11 +40,23 @@ WORKLOADS = {
 }
 
 
-def synth_video(U, T, seed, video_id):
-    """SURVEY.md §8d generator, vectorised over users (one PCG64 stream per video)."""
+def synth_video(U, T, seed, video_id, kind="random_walk"):
+    """SURVEY.md §8d generators, vectorised over users (one PCG64 stream per video).
+    random_walk: independent smooth walks (the default workload); uniform: uniform on the sphere,
+    no locality at all; clustered: everybody within a few degrees of one moving attention point
+    (what real audiences do: same-row / same-tile contention)."""
     rng = np.random.default_rng(seed + video_id * 10**6)
-    mu = np.mod(0.5 + np.cumsum(rng.normal(0.0, 0.01, (T, U)), axis=0), 1.0)
-    mv = np.clip(0.5 + np.cumsum(rng.normal(0.0, 0.005, (T, U)), axis=0), 0.0, 1.0)
+    if kind == "uniform":
+        mu = rng.random((T, U))
+        mv = np.clip(np.arccos(1.0 - 2.0 * rng.random((T, U))) / np.pi, 0.0, 1.0)
+    elif kind == "clustered":
+        cu = np.mod(0.5 + np.cumsum(rng.normal(0.0, 0.004, (T, 1)), axis=0), 1.0)
+        cv = np.clip(0.5 + np.cumsum(rng.normal(0.0, 0.002, (T, 1)), axis=0), 0.2, 0.8)
+        mu = np.mod(cu + rng.normal(0.0, 0.02, (T, U)), 1.0)
+        mv = np.clip(cv + rng.normal(0.0, 0.02, (T, U)), 0.0, 1.0)
+    else:
+        mu = np.mod(0.5 + np.cumsum(rng.normal(0.0, 0.01, (T, U)), axis=0), 1.0)
+        mv = np.clip(0.5 + np.cumsum(rng.normal(0.0, 0.005, (T, U)), axis=0), 0.0, 1.0)
     return np.ascontiguousarray(mu), np.ascontiguousarray(mv)
 
 
@@ -78,6 +90,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--data", default="random_walk", choices=["random_walk", "uniform", "clustered"],
+                    help="synthetic sample distribution (default: SURVEY §8d random walks)")
     ap.add_argument("--shard", default="videos", choices=["videos", "frames"],
                     help="N > 1: one video per GPU (weak scaling, default) or ONE video cut along the frame "
                          "axis with a 1-frame halo in transition mode (strong scaling, BASELINE config 5)")
@@ -106,7 +120,7 @@ def main():
     if strong:
         # every rank synthesises the same video and keeps its block of rows (+ halo frame)
         from viewport_entropy_toolkit import _dist
-        mu_h, mv_h = synth_video(U, T, args.seed, 0)
+        mu_h, mv_h = synth_video(U, T, args.seed, 0, args.data)
         if mode == "transition":
             r0, r1, f0, f1 = _dist.transition_frame_block(T, rank, world)
         else:
@@ -114,7 +128,7 @@ def main():
         mu_h, mv_h = np.ascontiguousarray(mu_h[f0:f1]), np.ascontiguousarray(mv_h[f0:f1])
         T = f1 - f0
     else:
-        mu_h, mv_h = synth_video(U, T, args.seed, rank)
+        mu_h, mv_h = synth_video(U, T, args.seed, rank, args.data)
     mu = torch.from_numpy(mu_h).to(dev)
     mv = torch.from_numpy(mv_h).to(dev)
     R = T if mode == "spatial" else T - 1
@@ -205,7 +219,7 @@ def main():
         out = {
             "metric": "viewport samples/sec", "value": samples_per_step / (ms_per_step * 1e-3), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if args.data == "random_walk" else f"synthetic ({args.data})",
             "config": {"workload": f"{args.workload}: {world} video(s) x {U} users x {T} frames, "
                                    f"tile_counts={tcs}, {mode}, "
                                    f"use_weight_distribution={weighted}, fov=120, W=100, H=200",
