@@ -1,15 +1,25 @@
 // vet_kernels.hpp — gfx950 (MI355X, CDNA4) device code of the viewport -> tile -> entropy path.
 //
 // Kernels (wave = 64 lanes everywhere):
-//   k_grid_dirs      axis tables -> rounded + normalised direction per pixel (py,px)
-//   k_nearest_lut    direction -> nearest lattice tile (FP64 arg-max of the normalised dot,
-//                    lowest index on ties), one LUT per lattice
-//   k_spatial        per frame: samples -> direction ids -> (weighted) tile histogram in LDS
-//                    (64-bit fixed point, order independent => bit-reproducible) -> Shannon
-//                    entropy; lane = tile, the wave walks the frame's users
-//   k_transition     per frame pair: (prior tile, current tile) pairs -> bucket statistics in
-//                    LDS (integer atomics + one small hash table) -> transition entropy
-//   k_finalize       mean over the plan's lattices
+//   plan tables (once per plan)
+//     k_grid_dirs      axis tables -> rounded + normalised direction per pixel (py,px)
+//     k_nearest_lut    direction -> nearest lattice tile (FP64 arg-max of the normalised dot,
+//                      lowest index on ties), one LUT per lattice
+//     k_wtab           direction -> ELL row of (tile, FoV weight) pairs, exact ocml acos / pow
+//     k_log2_table     log2(k), k <= 4096, for the integer-count entropies
+//   spatial entropy, FoV-weighted
+//     k_spatial_lut    table formulation: per frame, samples -> direction ids -> gather of the
+//                      users' rows into 64-bit integer LDS histograms (all lattices in one launch)
+//                      -> Shannon entropy; results are order independent, hence bit-reproducible
+//     k_spatial_w      sweep formulation (few samples per plan): lane = tile, FP64 cone test per
+//                      (user, tile), ballot-compacted full-wave weight evaluation
+//   spatial entropy, nearest-tile (unweighted) and naive lat/lon-grid mode
+//     k_spatial_u_lds  persistent stream with the nearest LUT in LDS (HBM-bound)
+//     k_spatial_u      generic fallback (LUT gathered from global memory)
+//   transition entropy
+//     k_transition     per frame pair: (prior tile, current tile) pairs -> bucket statistics in
+//                      LDS (integer atomics + one small hash table) -> transition entropy
+//   k_finalize         mean over the plan's lattices where they ran as separate launches
 //
 // No MFMA: there is no dense contraction on this path.  Reference citations are relative to
 // /root/reference/src/viewport_entropy_toolkit/.
@@ -25,14 +35,6 @@ constexpr unsigned EMPTY_KEY = 0xFFFFFFFFu;
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would
-// serialise a register prefetch issued just before it.
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
