@@ -1,0 +1,75 @@
+"""GPU: hypothesis-driven parity of the HIP path against the CPU oracle on small random problems
+(SURVEY.md §4 iii): random user / frame counts, absent samples, lattice sets, FoV and power,
+both weighted formulations, unweighted mode and transition mode."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import vet_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from viewport_entropy_toolkit import _native
+    return _native
+
+
+@pytest.fixture(scope="module")
+def engine(native):
+    return native.Engine.default()
+
+
+problem = st.fixed_dictionaries(dict(
+    U=st.integers(1, 70), T=st.integers(1, 12), seed=st.integers(0, 2 ** 31 - 1),
+    p_absent=st.sampled_from([0.0, 0.1, 0.5]),
+    tcs=st.lists(st.sampled_from([1, 2, 3, 20, 50, 64, 65, 100, 129, 250]), min_size=1, max_size=3),
+    fov=st.sampled_from([30.0, 90.0, 120.0, 150.0, 360.0]), power=st.sampled_from([0.5, 1.0, 2.0, 3.0]),
+    mode=st.sampled_from(["sweep", "table", "unweighted", "transition"]),
+    edge=st.booleans()))
+
+
+def make_samples(pr):
+    rng = np.random.default_rng(pr["seed"])
+    U, T = pr["U"], pr["T"]
+    if pr["edge"]:          # exact pixel boundaries, 0.0 and 1.0: the remap and clamp corners
+        mu = rng.integers(0, 101, (T, U)) / 100.0
+        mv = rng.integers(0, 201, (T, U)) / 200.0
+    else:
+        mu, mv = rng.random((T, U)), rng.random((T, U))
+    gone = rng.random((T, U)) < pr["p_absent"]
+    gone[:, 0] = False
+    mu[gone] = np.nan
+    mv[gone] = np.nan
+    return mu, mv
+
+
+@settings(max_examples=80, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(problem)
+def test_hip_matches_oracle(native, engine, pr):
+    mu, mv = make_samples(pr)
+    tcs, mode = pr["tcs"], pr["mode"]
+    weighted = mode in ("sweep", "table", "transition")
+    plan = native.Plan(engine, [vo.fibonacci_lattice(tc) for tc in tcs], pr["fov"], pr["power"], weighted, 100, 200)
+    plan.set_table_policy({"sweep": -1, "table": 1}.get(mode, 0))
+    try:
+        if mode == "transition":
+            if pr["T"] < 2:
+                return
+            res = plan.transition(mu=mu, mv=mv)
+            ent, pairs = vo.transition_series(mu, mv, 100, 200, tcs, closed_form=False)
+            assert np.array_equal(res["pairs"], pairs)
+            np.testing.assert_allclose(res["entropy"], ent, rtol=1e-9, equal_nan=True)
+        else:
+            res = plan.spatial(mu=mu, mv=mv, want_weights=True)
+            ent, assign, weights = vo.spatial_series(mu, mv, 100, 200, tcs, fov_angle=pr["fov"],
+                                                     power_factor=pr["power"], use_weight_distribution=weighted,
+                                                     want_weights=True)
+            assert np.array_equal(res["assign"], assign)
+            np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=2.0 ** -32 * pr["U"] + 1e-12)
+            ok = np.isfinite(ent)
+            assert np.array_equal(np.isnan(res["entropy"]), np.isnan(ent))
+            np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=1e-8, atol=1e-12)
+    finally:
+        plan.close()
