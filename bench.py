@@ -106,11 +106,18 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     multi = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ     # under torch.distributed.run: RCCL path
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # VET_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than
+    # ranks (ranks share devices, the gather goes through host memory); the real runs use RCCL.
+    backend = os.environ.get("VET_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from viewport_entropy_toolkit import _native, _quantiser
 
@@ -139,9 +146,10 @@ def main():
     # frame shards differ by at most one row: gather buffers of the largest shard
     Rg = R if not strong else (T_total - (1 if mode == "transition" else 0) + world - 1) // world
     send = ent if Rg == R else torch.zeros(Rg, dtype=torch.float64, device=dev)
-    gathered = [torch.empty(Rg, dtype=torch.float64, device=dev) for _ in range(world)] if (multi and rank == 0) else None
+    cdev = dev if backend == "nccl" else torch.device("cpu")
+    gathered = [torch.empty(Rg, dtype=torch.float64, device=cdev) for _ in range(world)] if (multi and rank == 0) else None
 
-    eng = _native.Engine(local_rank)
+    eng = _native.Engine(dev_index)
     t0 = time.perf_counter()
     plan = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in tcs], 120.0, 2.0, weighted, 100, 200)
     eng.synchronize()
@@ -158,7 +166,7 @@ def main():
         if multi:
             if send is not ent:
                 send[:R].copy_(ent)
-            dist.gather(send, gathered, dst=0)
+            dist.gather(send if backend == "nccl" else send.cpu(), gathered, dst=0)
 
     def fence():
         if multi:
@@ -190,7 +198,7 @@ def main():
     eng.profile_enable(False)
 
     if multi:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert int(status.sum().item()) == 0, "engine flagged out-of-range samples or empty frames"
@@ -220,10 +228,11 @@ def main():
             "metric": "viewport samples/sec", "value": samples_per_step / (ms_per_step * 1e-3), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if args.data == "random_walk" else f"synthetic ({args.data})",
-            "config": {"workload": f"{args.workload}: {world} video(s) x {U} users x {T} frames, "
+            "config": {"workload": f"{args.workload}: {1 if strong else world} video(s) x {U} users x "
+                                   f"{T_total if strong else T} frames, "
                                    f"tile_counts={tcs}, {mode}, "
                                    f"use_weight_distribution={weighted}, fov=120, W=100, H=200",
-                       "users": U, "frames": T, "tile_counts": tcs, "mode": mode,
+                       "users": U, "frames": T_total if strong else T, "tile_counts": tcs, "mode": mode,
                        "videos_per_gpu": 1, "parallelism": (f"one video cut into {world} frame blocks" if strong
                                        else f"one video per GPU x{world}")},
             "frames_per_s": (T_total if strong else R * world) / (ms_per_step * 1e-3),
