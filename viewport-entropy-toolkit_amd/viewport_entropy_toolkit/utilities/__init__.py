@@ -1,30 +1,23 @@
-"""Utilities of the entropy path (names as in the reference's ``utilities`` package)."""
+"""Utilities of the entropy path.
 
-from .data_utils import (
-    generate_fibonacci_lattice,
-    normalize_to_pixel,
-    pixel_to_spherical,
-    process_viewport_data,
-    format_trajectory_data,
-    validate_video_dimensions,
-)
-from .entropy_utils import (
-    EntropyConfig,
-    find_nearest_tile,
-    calculate_tile_weights,
-    compute_spatial_entropy,
-    compute_transition_entropy,
-    calculate_naive_tile_weights,
-    find_naive_tile_index,
-    compute_naive_spatial_entropy,
-)
-from .visualization_utils import VisualizationConfig, save_graph
+The operator-level functions keep the reference's names and signatures and run on the HIP
+engine; the ingest helpers are vectorised host code; visualisation is reduced to the
+configuration object and the entropy-over-time graph (rendering is outside the engine).
+"""
 
-__all__ = [
-    "generate_fibonacci_lattice", "normalize_to_pixel", "pixel_to_spherical", "process_viewport_data",
-    "format_trajectory_data", "validate_video_dimensions",
-    "EntropyConfig", "find_nearest_tile", "calculate_tile_weights", "compute_spatial_entropy",
-    "compute_transition_entropy", "calculate_naive_tile_weights", "find_naive_tile_index",
-    "compute_naive_spatial_entropy",
-    "VisualizationConfig", "save_graph",
-]
+from . import data_utils as _data, entropy_utils as _entropy, visualization_utils as _viz
+
+_PUBLIC = {
+    _data: ("generate_fibonacci_lattice", "normalize_to_pixel", "pixel_to_spherical", "process_viewport_data",
+            "format_trajectory_data", "validate_video_dimensions"),
+    _entropy: ("EntropyConfig", "find_nearest_tile", "calculate_tile_weights", "compute_spatial_entropy",
+               "compute_transition_entropy", "calculate_naive_tile_weights", "find_naive_tile_index",
+               "compute_naive_spatial_entropy"),
+    _viz: ("VisualizationConfig", "save_graph"),
+}
+for _module, _names in _PUBLIC.items():
+    for _name in _names:
+        globals()[_name] = getattr(_module, _name)
+
+__all__ = [name for names in _PUBLIC.values() for name in names]
+del _module, _names, _name
