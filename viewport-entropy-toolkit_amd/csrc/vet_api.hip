@@ -378,6 +378,9 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
                 long grid = (long)c->n_cu * 2;
                 if (const char* e = getenv("VET_U_WGS_PER_CU")) grid = (long)c->n_cu * atoi(e);
                 if (grid > nblk) grid = nblk;
+                // even rounds: every persistent workgroup walks the same number of blocks (no tail)
+                const long rounds = (nblk + grid - 1) / grid;
+                grid = (nblk + rounds - 1) / rounds;
                 ProfScope ps(c, s, KID_SPATIAL);
                 hipLaunchKernelGGL(vet::k_spatial_u_lds, dim3((unsigned)grid), dim3(THREADS), lds, s, q);
                 HIP_TRY(hipGetLastError());
