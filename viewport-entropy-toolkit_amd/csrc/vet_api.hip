@@ -58,6 +58,9 @@ struct vet_ctx {
     void* ws = nullptr;
     size_t ws_bytes = 0;
     double* d_log2 = nullptr;      // log2(k), k = 0..4096
+    // grow-only device staging buffers of the host-buffer entry points (no hipMalloc per call)
+    void* pool[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t pool_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // profiling
     bool profiling = false;
     std::vector<EventPair> pending;
@@ -507,6 +510,7 @@ int vet_destroy(vet_ctx* c) {
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     if (c->ws) (void)hipFree(c->ws);
     if (c->d_log2) (void)hipFree(c->d_log2);
+    for (void* q : c->pool) if (q) (void)hipFree(q);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return VET_OK;
@@ -778,7 +782,7 @@ int vet_transition_entropy_ids(vet_plan* pl, const int32_t* d_ids, int U, int T,
 }
 
 // ------------------------------------------------------------------------------------------------
-// host-buffer variants: stage through freshly allocated device buffers (not the hot path)
+// host-buffer variants: stage through the context's grow-only device buffers (synchronous)
 namespace {
 struct DevBuf {
     void* p = nullptr;
@@ -786,6 +790,21 @@ struct DevBuf {
     hipError_t alloc(size_t b) { return hipMalloc(&p, b ? b : 8); }
 };
 }  // namespace
+
+// slot-indexed staging buffer of at least `bytes` bytes (kept by the context between calls)
+static int pooled(vet_ctx* c, int slot, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 8;
+    if (c->pool_cap[slot] < bytes) {
+        if (c->pool[slot]) HIP_TRY(hipFree(c->pool[slot]));
+        c->pool[slot] = nullptr; c->pool_cap[slot] = 0;
+        const size_t want = bytes + bytes / 8;
+        HIP_TRY(hipMalloc(&c->pool[slot], want));
+        c->pool_cap[slot] = want;
+    }
+    *out = c->pool[slot];
+    return VET_OK;
+}
+#define POOL(slot, bytes, var) do { int rc_ = pooled(c, slot, bytes, &var); if (rc_) return rc_; } while (0)
 
 static int run_host(vet_plan* pl, bool transition, const double* h_mu, const double* h_mv, const int32_t* h_ids,
                     int U, int T, double* h_entropy, int32_t* h_a, void* h_b, int32_t* h_c) {
@@ -800,43 +819,44 @@ static int run_host(vet_plan* pl, bool transition, const double* h_mu, const dou
     const size_t S = (size_t)U * T;
     const int R = transition ? T - 1 : T;
     const int n0 = pl->lat[0].n;
-    DevBuf mu, mv, id, ent, a, b, cc, st;
+    void *mu = nullptr, *mv = nullptr, *id = nullptr, *ent = nullptr, *a = nullptr, *b = nullptr, *cc = nullptr,
+         *st = nullptr;
     if (ids) {
-        HIP_TRY(id.alloc(S * 4));
-        HIP_TRY(hipMemcpyAsync(id.p, h_ids, S * 4, hipMemcpyHostToDevice, s));
+        POOL(0, S * 4, id);
+        HIP_TRY(hipMemcpyAsync(id, h_ids, S * 4, hipMemcpyHostToDevice, s));
     } else {
-        HIP_TRY(mu.alloc(S * 8));
-        HIP_TRY(mv.alloc(S * 8));
-        HIP_TRY(hipMemcpyAsync(mu.p, h_mu, S * 8, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(mv.p, h_mv, S * 8, hipMemcpyHostToDevice, s));
+        POOL(0, S * 8, mu);
+        POOL(1, S * 8, mv);
+        HIP_TRY(hipMemcpyAsync(mu, h_mu, S * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(mv, h_mv, S * 8, hipMemcpyHostToDevice, s));
     }
-    HIP_TRY(ent.alloc((size_t)(R > 0 ? R : 1) * 8));
+    POOL(2, (size_t)(R > 0 ? R : 1) * 8, ent);
     const size_t a_bytes = transition ? (size_t)(R > 0 ? R : 0) * U * 2 * 4 : S * 4;
     const size_t b_bytes = transition ? (size_t)(R > 0 ? R : 0) * n0 * 4 : (size_t)T * n0 * 8;
-    if (h_a) HIP_TRY(a.alloc(a_bytes));
-    if (h_b) HIP_TRY(b.alloc(b_bytes));
-    HIP_TRY(cc.alloc((size_t)(R > 0 ? R : 1) * 4));
-    HIP_TRY(st.alloc(8));
-    HIP_TRY(hipMemsetAsync(st.p, 0, 8, s));
+    if (h_a) POOL(3, a_bytes, a);
+    if (h_b) POOL(4, b_bytes, b);
+    POOL(5, (size_t)(R > 0 ? R : 1) * 4, cc);
+    POOL(6, 8, st);
+    HIP_TRY(hipMemsetAsync(st, 0, 8, s));
     if (transition) {
-        rc = ids ? vet_transition_entropy_ids(pl, (const int32_t*)id.p, U, T, (double*)ent.p, (int32_t*)a.p,
-                                              (int32_t*)b.p, (int32_t*)cc.p, (int32_t*)st.p, s)
-                 : vet_transition_entropy(pl, (const double*)mu.p, (const double*)mv.p, U, T, (double*)ent.p,
-                                          (int32_t*)a.p, (int32_t*)b.p, (int32_t*)cc.p, (int32_t*)st.p, s);
+        rc = ids ? vet_transition_entropy_ids(pl, (const int32_t*)id, U, T, (double*)ent, (int32_t*)a, (int32_t*)b,
+                                              (int32_t*)cc, (int32_t*)st, s)
+                 : vet_transition_entropy(pl, (const double*)mu, (const double*)mv, U, T, (double*)ent,
+                                          (int32_t*)a, (int32_t*)b, (int32_t*)cc, (int32_t*)st, s);
     } else {
-        rc = ids ? vet_spatial_entropy_ids(pl, (const int32_t*)id.p, U, T, (double*)ent.p, (int32_t*)a.p,
-                                           (double*)b.p, (int32_t*)cc.p, (int32_t*)st.p, s)
-                 : vet_spatial_entropy(pl, (const double*)mu.p, (const double*)mv.p, U, T, (double*)ent.p,
-                                       (int32_t*)a.p, (double*)b.p, (int32_t*)cc.p, (int32_t*)st.p, s);
+        rc = ids ? vet_spatial_entropy_ids(pl, (const int32_t*)id, U, T, (double*)ent, (int32_t*)a, (double*)b,
+                                           (int32_t*)cc, (int32_t*)st, s)
+                 : vet_spatial_entropy(pl, (const double*)mu, (const double*)mv, U, T, (double*)ent, (int32_t*)a,
+                                       (double*)b, (int32_t*)cc, (int32_t*)st, s);
     }
     if (rc) { (void)hipStreamSynchronize(s); return rc; }
     int32_t status[2] = {0, 0};
     if (R > 0) {
-        HIP_TRY(hipMemcpyAsync(h_entropy, ent.p, (size_t)R * 8, hipMemcpyDeviceToHost, s));
-        if (h_a) HIP_TRY(hipMemcpyAsync(h_a, a.p, a_bytes, hipMemcpyDeviceToHost, s));
-        if (h_b) HIP_TRY(hipMemcpyAsync(h_b, b.p, b_bytes, hipMemcpyDeviceToHost, s));
-        if (h_c) HIP_TRY(hipMemcpyAsync(h_c, cc.p, (size_t)R * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(status, st.p, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h_entropy, ent, (size_t)R * 8, hipMemcpyDeviceToHost, s));
+        if (h_a) HIP_TRY(hipMemcpyAsync(h_a, a, a_bytes, hipMemcpyDeviceToHost, s));
+        if (h_b) HIP_TRY(hipMemcpyAsync(h_b, b, b_bytes, hipMemcpyDeviceToHost, s));
+        if (h_c) HIP_TRY(hipMemcpyAsync(h_c, cc, (size_t)R * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(status, st, 8, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(hipStreamSynchronize(s));
     if (status[0]) return fail(VET_ERR_RANGE, "Normalized coordinates must be between 0 and 1 (%d samples)", status[0]);
