@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import logging
 import os
+import time
 from concurrent.futures import ThreadPoolExecutor
 from datetime import datetime
 from pathlib import Path
@@ -80,6 +81,7 @@ class _EntropyAnalyzerBase:
         self._dense = None                # (frame_times[T], mu[T,U], mv[T,U], user names)
         self._plan: Optional[_native.Plan] = None
         self._plan_key = None
+        self.last_timing: Dict[str, float] = {}   # seconds / rates of the last ingest and compute
 
     # ------------------------------------------------------------------ ingest
     def process_directory(self, directory: Path) -> None:
@@ -87,6 +89,7 @@ class _EntropyAnalyzerBase:
         directory = Path(directory)
         if not directory.exists():
             raise FileNotFoundError(f"Directory not found: {directory}")
+        t_start = time.perf_counter()
         try:
             files = list(directory.glob("*.csv"))          # glob order = user (column) order, as in the reference
             read = lambda fp: _ingest.read_track(fp, self.config.video_width, self.config.video_height)  # noqa: E731
@@ -100,6 +103,7 @@ class _EntropyAnalyzerBase:
             self._dense = (times, mu, mv, [name for name, _ in trajectory_data])
             self._data_cache = _DataCache(trajectory_data)
             self._entropy_results = None
+            self.last_timing = {"ingest_s": time.perf_counter() - t_start}
         except Exception as e:  # noqa: BLE001
             self._logger.error(f"Error processing directory {directory}: {str(e)}")
             raise ValidationError(f"Failed to process directory: {str(e)}")
@@ -182,6 +186,14 @@ class _EntropyAnalyzerBase:
         except Exception as e:  # noqa: BLE001
             self._logger.error(f"Analysis failed: {str(e)}")
             raise
+
+    def _record_compute(self, seconds: float, n_samples: int, n_rows: int) -> None:
+        """Throughput counters of the last engine call (samples/s, frames/s)."""
+        self.last_timing.update(compute_s=seconds, samples=float(n_samples), frames=float(n_rows),
+                                samples_per_s=n_samples / max(seconds, 1e-12),
+                                frames_per_s=n_rows / max(seconds, 1e-12))
+        self._logger.info("entropy of %d frames x %d samples in %.3f ms (%.3g samples/s)", n_rows, n_samples,
+                          seconds * 1e3, n_samples / max(seconds, 1e-12))
 
     def compute_entropy(self) -> pd.DataFrame:  # pragma: no cover - overridden
         raise NotImplementedError

@@ -10,6 +10,7 @@ carries ``None`` in ``tile_weights`` / ``tile_assignments``."""
 from __future__ import annotations
 
 import logging
+import time
 from typing import Optional
 
 import numpy as np
@@ -38,6 +39,7 @@ class NaiveSpatialEntropyAnalyzer(_EntropyAnalyzerBase):
         self._dense = None
         self._plan = None
         self._plan_key = None
+        self.last_timing = {}
 
     def _naive_plan(self) -> "_native.Plan":
         cfg = self.config
@@ -69,6 +71,7 @@ class NaiveSpatialEntropyAnalyzer(_EntropyAnalyzerBase):
         if not self._data_cache or self._dense is None:
             raise ValidationError("No data available. Call process_directory first.")
         times, mu, mv, _ = self._dense
+        t_start = time.perf_counter()
         try:
             res = self._naive_plan().spatial(mu=mu, mv=mv, want_assign=False, want_weights=False)
         except _native.NativeError as e:
@@ -77,6 +80,7 @@ class NaiveSpatialEntropyAnalyzer(_EntropyAnalyzerBase):
             if e.code == _native.VET_ERR_EMPTY:
                 raise ValidationError("Empty radial points dictionary")
             raise
+        self._record_compute(time.perf_counter() - t_start, mu.size, len(times))
         self._entropy_results = pd.DataFrame({
             "time": times,
             "entropy": res["entropy"],

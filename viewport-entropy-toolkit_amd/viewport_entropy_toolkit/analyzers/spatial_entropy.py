@@ -5,6 +5,7 @@ analyzers/spatial_entropy.py:107-164), computed by the HIP engine in one call pe
 from __future__ import annotations
 
 import logging
+import time
 
 import pandas as pd
 
@@ -25,6 +26,7 @@ class SpatialEntropyAnalyzer(_EntropyAnalyzerBase):
 
     def compute_entropy(self) -> pd.DataFrame:
         kind, times, a, b, names = self._samples()
+        t_start = time.perf_counter()
         try:
             if kind == "grid":
                 res = self._get_plan().spatial(mu=a, mv=b, want_assign=True, want_weights=True)
@@ -40,6 +42,7 @@ class SpatialEntropyAnalyzer(_EntropyAnalyzerBase):
             if e.code == _native.VET_ERR_EMPTY:
                 raise ValidationError("Empty vector dictionary")
             raise
+        self._record_compute(time.perf_counter() - t_start, a.size, len(res["entropy"]))
         tiles = self._fibonacci_vectors[self.config.tile_counts[0]]
         self._entropy_results = pd.DataFrame({
             "time": times,

@@ -6,6 +6,7 @@ Row 0 of the frame table only seeds the prior, so the result has T-1 rows."""
 from __future__ import annotations
 
 import logging
+import time
 
 import pandas as pd
 
@@ -25,6 +26,7 @@ class TransitionEntropyAnalyzer(_EntropyAnalyzerBase):
 
     def compute_entropy(self) -> pd.DataFrame:
         kind, times, a, b, names = self._samples()
+        t_start = time.perf_counter()
         try:
             if kind == "grid":
                 res = self._get_plan().transition(mu=a, mv=b, want_pairs=True, want_srccount=True)
@@ -41,6 +43,7 @@ class TransitionEntropyAnalyzer(_EntropyAnalyzerBase):
                 # the reference divides by the (zero) number of common users
                 raise ZeroDivisionError("float division by zero")
             raise
+        self._record_compute(time.perf_counter() - t_start, a.size, len(res["entropy"]))
         tiles = self._fibonacci_vectors[self.config.tile_counts[0]]
         self._entropy_results = pd.DataFrame({
             "time": times[1:],
