@@ -367,7 +367,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         p.log2_tab = c->d_log2;
         p.full_norm = (L.binned && pl->weighted) ? 1 : 0;
         p.norm_n = L.norm_n;
-        if (!hist_weighted && !FROM_IDS && (U & 1) == 0 && U <= 4096 && !p.weights && !getenv("VET_U_NO_LDS")) {
+        if (!hist_weighted && !FROM_IDS && (U & 1) == 0 && U <= 4096 && !getenv("VET_U_NO_LDS")) {
             // persistent variant with the nearest LUT in LDS: FB frames x U/2 pairs <= 2048 per round
             constexpr int THREADS = 1024;
             int FB = 2048 / (U / 2);
@@ -385,7 +385,8 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
                 const long rounds = (nblk + grid - 1) / grid;
                 grid = (nblk + rounds - 1) / rounds;
                 ProfScope ps(c, s, KID_SPATIAL);
-                hipLaunchKernelGGL(vet::k_spatial_u_lds, dim3((unsigned)grid), dim3(THREADS), lds, s, q);
+                if (q.weights) hipLaunchKernelGGL(vet::k_spatial_u_lds<true>, dim3((unsigned)grid), dim3(THREADS), lds, s, q);
+                else hipLaunchKernelGGL(vet::k_spatial_u_lds<false>, dim3((unsigned)grid), dim3(THREADS), lds, s, q);
                 HIP_TRY(hipGetLastError());
                 continue;
             }
@@ -681,7 +682,8 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
         }
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));

@@ -770,6 +770,7 @@ __global__ void k_spatial_u(const SpatialParams p) {
 // k = 1..U, copied from a per-context table (keeps ocml's log2 out of this kernel: 64 VGPRs, no spills).
 // LDS: lut u16 [n_dirs] | lg f64 [U+1] | cnt u32 [FB][n]
 // ------------------------------------------------------------------------------------------
+template <bool WEIGHTS>      // also write the per-frame tile counts (the analyzers' tile_weights)
 __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PPT = 2;
@@ -825,9 +826,11 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
             np = wave_sum(np);
             const double tw = (double)np, lgn = lg[np], inv_tw = 1.0 / tw;
             double h = 0.0;
+            double* wout = WEIGHTS ? p.weights + (f0 + f) * (long)p.n : nullptr;
             for (int t = lane; t < p.n; t += WAVE) {
                 const unsigned v = row[t];
                 if (v) h -= ((double)v * inv_tw) * (lg[v] - lgn);
+                if (WEIGHTS) wout[t] = (double)v;
                 row[t] = 0u;
             }
             h = wave_sum(h);
