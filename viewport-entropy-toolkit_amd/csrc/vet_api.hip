@@ -367,10 +367,12 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         p.log2_tab = c->d_log2;
         p.full_norm = (L.binned && pl->weighted) ? 1 : 0;
         p.norm_n = L.norm_n;
-        if (!hist_weighted && !FROM_IDS && (U & 1) == 0 && U <= 4096 && !getenv("VET_U_NO_LDS")) {
-            // persistent variant with the nearest LUT in LDS: FB frames x U/2 pairs <= 2048 per round
+        if (!hist_weighted && !FROM_IDS && U <= 4096 && !getenv("VET_U_NO_LDS")) {
+            // persistent variant with the nearest LUT in LDS: a round is 4096 users = FB frames
+            // (2048 pairs with 16-byte loads when U is even, 4096 single users otherwise)
             constexpr int THREADS = 1024;
-            int FB = 2048 / (U / 2);
+            const bool pairs = (U & 1) == 0;
+            int FB = 4096 / U;
             if (FB > 64) FB = 64;
             const size_t lds = (((size_t)pl->n_dirs * 2 + 15) & ~(size_t)15) + (size_t)(U + 1) * 8 +
                                ((((size_t)FB * L.n + 1) & ~(size_t)1) * 4) + (size_t)FB * (THREADS / 64) * 8 + FB * 4 + 16;
@@ -385,8 +387,10 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
                 const long rounds = (nblk + grid - 1) / grid;
                 grid = (nblk + rounds - 1) / rounds;
                 ProfScope ps(c, s, KID_SPATIAL);
-                if (q.weights) hipLaunchKernelGGL(vet::k_spatial_u_lds<true>, dim3((unsigned)grid), dim3(THREADS), lds, s, q);
-                else hipLaunchKernelGGL(vet::k_spatial_u_lds<false>, dim3((unsigned)grid), dim3(THREADS), lds, s, q);
+                const void* fn = q.weights ? (pairs ? (const void*)vet::k_spatial_u_lds<true, true> : (const void*)vet::k_spatial_u_lds<true, false>)
+                                           : (pairs ? (const void*)vet::k_spatial_u_lds<false, true> : (const void*)vet::k_spatial_u_lds<false, false>);
+                void* args[] = {(void*)&q};
+                HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(THREADS), args, lds, s));
                 HIP_TRY(hipGetLastError());
                 continue;
             }
@@ -682,8 +686,10 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
         }
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));

@@ -770,7 +770,9 @@ __global__ void k_spatial_u(const SpatialParams p) {
 // k = 1..U, copied from a per-context table (keeps ocml's log2 out of this kernel: 64 VGPRs, no spills).
 // LDS: lut u16 [n_dirs] | lg f64 [U+1] | cnt u32 [FB][n]
 // ------------------------------------------------------------------------------------------
-template <bool WEIGHTS>      // also write the per-frame tile counts (the analyzers' tile_weights)
+// WEIGHTS: also write the per-frame tile counts (the analyzers' tile_weights).  PAIRS: 16-byte loads,
+// two users per lane (even U); otherwise one user per lane with 8-byte loads, any U.
+template <bool WEIGHTS, bool PAIRS>
 __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PPT = 2;
@@ -786,35 +788,58 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
     for (int i = tid; i < FB * p.n; i += blockDim.x) cnt[i] = 0u;
     __syncthreads();
     bool bad = false;
-    const int ppf = p.U >> 1;                                                    // pairs per frame
-    const float inv_ppf = 1.0f / (float)ppf;
+    const int ipf = PAIRS ? p.U >> 1 : p.U;                                      // items (pairs or users) per frame
+    const float inv_ipf = 1.0f / (float)ipf;
     const long nblocks = ((long)p.T + FB - 1) / FB;
     for (long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         const long f0 = blk * FB;
         const int nf = (int)min((long)FB, (long)p.T - f0);
-        const int npairs = nf * ppf;
-        const double2* mu2 = (const double2*)(p.src.mu + f0 * (long)p.U);
-        const double2* mv2 = (const double2*)(p.src.mv + f0 * (long)p.U);
-        int2* out2 = (int2*)(p.assign ? p.assign + f0 * (long)p.U : nullptr);
-        double2 a[PPT], b[PPT];
+        const int nitems = nf * ipf;
+        if (PAIRS) {
+            const double2* mu2 = (const double2*)(p.src.mu + f0 * (long)p.U);
+            const double2* mv2 = (const double2*)(p.src.mv + f0 * (long)p.U);
+            int2* out2 = (int2*)(p.assign ? p.assign + f0 * (long)p.U : nullptr);
+            double2 a[PPT], b[PPT];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int i = tid + k * (int)blockDim.x;
-            if (i < npairs) { a[k] = mu2[i]; b[k] = mv2[i]; }
-        }
+            for (int k = 0; k < PPT; ++k) {
+                const int i = tid + k * (int)blockDim.x;
+                if (i < nitems) { a[k] = mu2[i]; b[k] = mv2[i]; }
+            }
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int i = tid + k * (int)blockDim.x;
-            if (i < npairs) {
-                const int fl = (int)(((float)i + 0.5f) * inv_ppf);               // exact: i < 2^12
-                const int id0 = grid_dir(a[k].x, b[k].x, p.src.W, p.src.H, bad);
-                const int id1 = grid_dir(a[k].y, b[k].y, p.src.W, p.src.H, bad);
-                const int n0 = id0 >= 0 ? (int)lut[id0] : -1;
-                const int n1 = id1 >= 0 ? (int)lut[id1] : -1;
-                unsigned* row = cnt + (size_t)fl * p.n;
-                if (n0 >= 0) atomicAdd(&row[n0], 1u);
-                if (n1 >= 0) atomicAdd(&row[n1], 1u);
-                if (out2) out2[i] = make_int2(n0, n1);
+            for (int k = 0; k < PPT; ++k) {
+                const int i = tid + k * (int)blockDim.x;
+                if (i < nitems) {
+                    const int fl = (int)(((float)i + 0.5f) * inv_ipf);           // exact: i < 2^12
+                    const int id0 = grid_dir(a[k].x, b[k].x, p.src.W, p.src.H, bad);
+                    const int id1 = grid_dir(a[k].y, b[k].y, p.src.W, p.src.H, bad);
+                    const int n0 = id0 >= 0 ? (int)lut[id0] : -1;
+                    const int n1 = id1 >= 0 ? (int)lut[id1] : -1;
+                    unsigned* row = cnt + (size_t)fl * p.n;
+                    if (n0 >= 0) atomicAdd(&row[n0], 1u);
+                    if (n1 >= 0) atomicAdd(&row[n1], 1u);
+                    if (out2) out2[i] = make_int2(n0, n1);
+                }
+            }
+        } else {
+            const double* mu1 = p.src.mu + f0 * (long)p.U;
+            const double* mv1 = p.src.mv + f0 * (long)p.U;
+            int* out1 = p.assign ? p.assign + f0 * (long)p.U : nullptr;
+            double a[2 * PPT], b[2 * PPT];
+#pragma unroll
+            for (int k = 0; k < 2 * PPT; ++k) {
+                const int i = tid + k * (int)blockDim.x;
+                if (i < nitems) { a[k] = mu1[i]; b[k] = mv1[i]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 2 * PPT; ++k) {
+                const int i = tid + k * (int)blockDim.x;
+                if (i < nitems) {
+                    const int fl = (int)(((float)i + 0.5f) * inv_ipf);           // exact: i < 2^13
+                    const int id0 = grid_dir(a[k], b[k], p.src.W, p.src.H, bad);
+                    const int n0 = id0 >= 0 ? (int)lut[id0] : -1;
+                    if (n0 >= 0) atomicAdd(&cnt[(size_t)fl * p.n + n0], 1u);
+                    if (out1) out1[i] = n0;
+                }
             }
         }
         __syncthreads();
