@@ -117,7 +117,7 @@ int64_t vet_plan_n_dirs(const vet_plan *plan);
 /* Weighted spatial mode has two formulations with identical results up to the fixed-point
  * resolution: (a) brute force, every sample sweeps every tile (FP64 VALU bound); (b) direction
  * weight table, built once per plan and gathered per sample (memory bound).  policy: 0 auto
- * (table once the plan has processed at least as many samples as it has directions), 1 always table,
+ * (table once the plan has processed 16 samples per direction of its table), 1 always table,
  * -1 never.  vet_plan_table_stride: row length of lattice k's table, 0 = not built (yet),
  * -1 = too large. */
 int vet_plan_set_table_policy(vet_plan *plan, int policy);

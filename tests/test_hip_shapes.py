@@ -120,10 +120,9 @@ def test_heavily_clustered_users(native, engine):
 
 
 def test_table_formulation_on_a_larger_grid(native, engine):
-    """640x480 pixels: 308 k directions; a 400 k-sample video makes the auto policy pick the
-    direction weight table (118 MB)."""
+    """640x480 pixels: 308 k directions; the direction weight table (118 MB) on a 400 k-sample video."""
     mu, mv = video(1000, 400, seed=99, p_absent=0.02)
-    plan = plan_for(native, engine, [50], 640, 480)
+    plan = plan_for(native, engine, [50], 640, 480, policy=1)
     res = plan.spatial(mu=mu, mv=mv)
     assert plan.table_stride(0) > 0
     ent, assign, _ = vo.spatial_series(mu, mv, 640, 480, [50])

@@ -268,10 +268,12 @@ bool any_binned(const vet_plan* pl) {
 bool want_table(const vet_plan* pl, int U, int T) {
     if (!pl->weighted || pl->table_policy < 0 || any_binned(pl)) return false;
     if (pl->table_policy > 0) return true;
-    // rows are reused on average at least once over the plan's lifetime (an analyzer usually
-    // serves many videos), or the tables exist already
+    // Tables exist already, or they pay for themselves: building a row costs about 30 times what
+    // the sweep spends on one sample (k_wtab evaluates acos/pow for a whole row; measured 0.27 ms per
+    // 20 301 x 501 table vs 11.9 ms per 30.72 M x 501 sweep), and a gathered sample is ~6x cheaper
+    // than a swept one, so switch once the plan has seen 16 samples per direction.
     if (pl->lat[0].stride > 0) return true;
-    return pl->samples_seen + (long)U * T >= (long)pl->n_dirs;
+    return pl->samples_seen + (long)U * T >= 16 * (long)pl->n_dirs;
 }
 
 template <bool FROM_IDS>
