@@ -13,6 +13,17 @@ HERE = Path(__file__).resolve().parent
 LIB = HERE / "_build" / "libvet_oracle.so"
 
 
+def set_threads(n: int) -> None:
+    """OpenMP threads of the spatial port (frames are spread over them)."""
+    lib = load()
+    try:
+        omp = C.CDLL("libgomp.so.1")
+        omp.omp_set_num_threads(int(n))
+    except OSError:
+        pass
+    del lib
+
+
 def load(build: bool = True):
     if not LIB.exists() and build:
         subprocess.run(["make", "-C", str(HERE)], check=True, capture_output=True)

@@ -16,7 +16,8 @@
  * per sample (calculate_tile_weights, then find_nearest_tile); here one sweep feeds both.
  * The pixel -> Vector grid (trigonometry + decimal rounding) is supplied by the Python oracle.
  *
- * Build:  gcc -O2 -fPIC -shared -o _build/libvet_oracle.so vet_oracle.c -lm   (no -ffast-math)
+ * Build:  gcc -O2 -fopenmp -fPIC -shared -o _build/libvet_oracle.so vet_oracle.c -lm   (no -ffast-math)
+ *         Threads follow OMP_NUM_THREADS (bench.py times 1 thread and the box's core share).
  */
 #include <math.h>
 #include <stdint.h>
@@ -51,55 +52,66 @@ int oracle_spatial(const double *mu, const double *mv, int T, int U, int W, int 
     const double max_ang = (fov_deg / 2.0) * (M_PI / 180.0);
     int nmax = 0;
     for (int k = 0; k < K; ++k) if (n_tiles[k] > nmax) nmax = n_tiles[k];
-    double *hist = (double *)malloc(sizeof(double) * nmax);
-    char *touched = (char *)malloc(nmax);
     int rc = 0;
-    for (int t = 0; t < T && !rc; ++t) {
-        double total_entropy = 0.0;
-        for (int k = 0; k < K && !rc; ++k) {
-            const int n = n_tiles[k];
-            const double *tl = tiles[k];
-            memset(hist, 0, sizeof(double) * n);
-            memset(touched, 0, n);
-            double total_weight = 0.0;
-            int present = 0;
-            for (int u = 0; u < U; ++u) {
-                const long id = dir_id(mu[(long)t * U + u], mv[(long)t * U + u], W, H);
-                if (id == -2) { rc = -3; break; }
-                if (id < 0) { if (k == 0 && out_assign) out_assign[(long)t * U + u] = -1; continue; }
-                ++present;
-                const double *d = grid + 3 * id;
-                double best = 1e300;
-                int bi = 0;
-                for (int j = 0; j < n; ++j) {
-                    const double a = angle(d, tl + 3 * j);
-                    if (a < best) { best = a; bi = j; }
-                    if (weighted && a < max_ang) {
-                        const double w = pow((max_ang - a) / max_ang, power);
-                        hist[j] += w;
-                        touched[j] = 1;
-                        total_weight += w;
+    /* frames are independent: with -fopenmp (and OMP_NUM_THREADS > 1) they are spread over the host
+     * cores, each thread with its own histogram; without OpenMP this is the plain serial loop */
+#pragma omp parallel
+    {
+        double *hist = (double *)malloc(sizeof(double) * nmax);
+        char *touched = (char *)malloc(nmax);
+#pragma omp for schedule(static)
+        for (int t = 0; t < T; ++t) {
+            int frc = 0;
+            double total_entropy = 0.0;
+            for (int k = 0; k < K && !frc; ++k) {
+                const int n = n_tiles[k];
+                const double *tl = tiles[k];
+                memset(hist, 0, sizeof(double) * n);
+                memset(touched, 0, n);
+                double total_weight = 0.0;
+                int present = 0;
+                for (int u = 0; u < U; ++u) {
+                    const long id = dir_id(mu[(long)t * U + u], mv[(long)t * U + u], W, H);
+                    if (id == -2) { frc = -3; break; }
+                    if (id < 0) { if (k == 0 && out_assign) out_assign[(long)t * U + u] = -1; continue; }
+                    ++present;
+                    const double *d = grid + 3 * id;
+                    double best = 1e300;
+                    int bi = 0;
+                    for (int j = 0; j < n; ++j) {
+                        const double a = angle(d, tl + 3 * j);
+                        if (a < best) { best = a; bi = j; }
+                        if (weighted && a < max_ang) {
+                            const double w = pow((max_ang - a) / max_ang, power);
+                            hist[j] += w;
+                            touched[j] = 1;
+                            total_weight += w;
+                        }
                     }
+                    if (!weighted) { hist[bi] += 1.0; touched[bi] = 1; total_weight += 1.0; }
+                    if (k == 0 && out_assign) out_assign[(long)t * U + u] = bi;
                 }
-                if (!weighted) { hist[bi] += 1.0; touched[bi] = 1; total_weight += 1.0; }
-                if (k == 0 && out_assign) out_assign[(long)t * U + u] = bi;
+                if (frc) break;
+                if (!present) { frc = -4; break; }
+                double ent = 0.0;
+                for (int j = 0; j < n; ++j)
+                    if (touched[j]) {
+                        const double p = hist[j] / total_weight;
+                        ent -= p * log2(p);
+                    }
+                const double mx = (weighted || total_weight > n) ? max_entropy((double)n) : max_entropy(total_weight);
+                total_entropy += ent / mx;
+                if (k == 0 && out_weights0) memcpy(out_weights0 + (long)t * n, hist, sizeof(double) * n);
             }
-            if (rc) break;
-            if (!present) { rc = -4; break; }
-            double ent = 0.0;
-            for (int j = 0; j < n; ++j)
-                if (touched[j]) {
-                    const double p = hist[j] / total_weight;
-                    ent -= p * log2(p);
-                }
-            const double mx = (weighted || total_weight > n) ? max_entropy((double)n) : max_entropy(total_weight);
-            total_entropy += ent / mx;
-            if (k == 0 && out_weights0) memcpy(out_weights0 + (long)t * n, hist, sizeof(double) * n);
+            out_entropy[t] = total_entropy / K;
+            if (frc) {
+#pragma omp critical
+                if (!rc || frc > rc) rc = frc;
+            }
         }
-        out_entropy[t] = total_entropy / K;
+        free(hist);
+        free(touched);
     }
-    free(hist);
-    free(touched);
     return rc;
 }
 
