@@ -20,6 +20,14 @@ GOLDEN = ROOT / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box)")
+    # The built library is git-ignored: build it when a fresh checkout runs the tests before
+    # __graft_entry__.build() (hipcc cross-compiles gfx950 without a GPU).
+    lib = PKG_PARENT / "lib" / "libvet_hip.so"
+    if not lib.exists():
+        import shutil
+        import subprocess
+        if shutil.which("make") and (shutil.which("hipcc") or Path("/opt/rocm/bin/hipcc").exists()):
+            subprocess.run(["make", "-C", str(PKG_PARENT / "csrc")], check=False, capture_output=True)
 
 
 @pytest.fixture(scope="session")
