@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -10,7 +11,7 @@ import numpy as np
 from . import vet_oracle as vo
 
 HERE = Path(__file__).resolve().parent
-LIB = HERE / "_build" / "libvet_oracle.so"
+LIB = Path(os.environ.get("VET_ORACLE_LIB", HERE / "_build" / "libvet_oracle.so"))
 
 
 def set_threads(n: int) -> None:
