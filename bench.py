@@ -37,7 +37,10 @@ WORKLOADS = {
     "config3u": (1024, 30000, [500], "spatial", False),     # nearest-tile (unweighted) histogram
     "config4": (256, 10000, [50, 100, 200], "spatial", True),
     "config5": (512, 10000, [200], "transition", True),
+    # 64 config-2-sized videos per GPU in one launch (vet_spatial_entropy_batch); --loop runs them one by one
+    "config2x64": (64, 3000, [50, 100, 200], "spatial", True),
 }
+BATCH = {"config2x64": 64}
 
 
 def synth_video(U, T, seed, video_id, kind="random_walk"):
@@ -121,6 +124,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--data", default="random_walk", choices=["random_walk", "uniform", "clustered"],
                     help="synthetic sample distribution (default: SURVEY §8d random walks)")
+    ap.add_argument("--loop", action="store_true", help="batched workloads: one call per video instead of one launch")
     ap.add_argument("--shard", default="videos", choices=["videos", "frames"],
                     help="N > 1: one video per GPU (weak scaling, default) or ONE video cut along the frame "
                          "axis with a 1-frame halo in transition mode (strong scaling, BASELINE config 5)")
@@ -185,7 +189,28 @@ def main():
     plan_ms = (time.perf_counter() - t0) * 1e3
     stream = torch.cuda.current_stream().cuda_stream
 
+    n_batch = BATCH.get(args.workload, 1)
+    if n_batch > 1:
+        # n_batch videos of the workload's shape per GPU (different seeds), resident in HBM
+        import ctypes as C
+        mus = [torch.from_numpy(synth_video(U, T, args.seed, rank * n_batch + v, args.data)[0]).to(dev) for v in range(n_batch)]
+        mvs = [torch.from_numpy(synth_video(U, T, args.seed, rank * n_batch + v, args.data)[1]).to(dev) for v in range(n_batch)]
+        ents = [torch.empty(T, dtype=torch.float64, device=dev) for _ in range(n_batch)]
+        idxs = [torch.empty((T, U), dtype=torch.int32, device=dev) for _ in range(n_batch)]
+        vids = (_native.Video * n_batch)(*[_native.Video(mus[v].data_ptr(), mvs[v].data_ptr(), U, T, ents[v].data_ptr(),
+                                                         idxs[v].data_ptr(), None) for v in range(n_batch)])
+
     def step():
+        if n_batch > 1:
+            if args.loop:
+                for v in range(n_batch):
+                    plan.spatial_device(mus[v].data_ptr(), mvs[v].data_ptr(), U, T, ents[v].data_ptr(),
+                                        d_assign=idxs[v].data_ptr(), d_status=status.data_ptr(), stream=stream)
+            else:
+                plan.spatial_batch_device(vids, d_status=status.data_ptr(), stream=stream)
+            if multi:
+                dist.gather(ents[0], gathered, dst=0)
+            return
         if mode == "spatial":
             plan.spatial_device(mu.data_ptr(), mv.data_ptr(), U, T, ent.data_ptr(), d_assign=idx.data_ptr(),
                                 d_status=status.data_ptr(), stream=stream)
@@ -231,17 +256,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert int(status.sum().item()) == 0, "engine flagged out-of-range samples or empty frames"
-    e_host = ent.cpu().numpy()
+    e_host = (ents[-1] if n_batch > 1 else ent).cpu().numpy()
     assert np.isfinite(e_host).all()
 
     if rank == 0:
-        samples_per_step = U * T_total if strong else U * T * world
+        samples_per_step = (U * T_total if strong else U * T * world) * n_batch
         ms_per_step = elapsed / args.steps * 1e3
         # algorithmic bytes: 16 B in + 4 B (8 B transition) out per sample and 8 B of
         # entropy per frame, the samples counted once whatever the number of lattices; per launch of
         # the dominant kernel = per step / launches per step
         per_sample_out = 4 if mode == "spatial" else 8
-        alg_bytes_step = (16 + per_sample_out) * U * T + 8 * R
+        alg_bytes_step = ((16 + per_sample_out) * U * T + 8 * R) * n_batch
         launches_per_step = max(k_n / args.steps, 1.0)
         alg_bytes_launch = alg_bytes_step / launches_per_step
         avg_kernel_ms = k_ms / max(k_n, 1)
@@ -262,9 +287,9 @@ def main():
                                    f"tile_counts={tcs}, {mode}, "
                                    f"use_weight_distribution={weighted}, fov=120, W=100, H=200",
                        "users": U, "frames": T_total if strong else T, "tile_counts": tcs, "mode": mode,
-                       "videos_per_gpu": 1, "parallelism": (f"one video cut into {world} frame blocks" if strong
+                       "videos_per_gpu": n_batch, "batched_launch": bool(n_batch > 1 and not args.loop), "parallelism": (f"one video cut into {world} frame blocks" if strong
                                        else f"one video per GPU x{world}")},
-            "frames_per_s": (T_total if strong else R * world) / (ms_per_step * 1e-3),
+            "frames_per_s": (T_total if strong else R * world) * n_batch / (ms_per_step * 1e-3),
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes_launch,

@@ -159,6 +159,24 @@ int vet_transition_entropy_ids(vet_plan *plan, const int32_t *d_ids, int n_users
                                double *d_entropy, int32_t *d_pairs, int32_t *d_srccount,
                                int32_t *d_common, int32_t *d_status, void *stream);
 
+/* ---- many videos, one launch ---------------------------------------------------
+ * Short videos are launch-bound one call at a time; a batch shares one grid (weighted table
+ * formulation; other modes run video by video inside the call).  Lattice 0's tile weights are not
+ * produced by the batched form.  Asynchronous on ``stream`` like vet_spatial_entropy. */
+typedef struct vet_video {
+    const double *d_mu, *d_mv;   /* [n_frames * n_users], frame-major */
+    int n_users, n_frames;
+    double *d_entropy;           /* [n_frames] */
+    int32_t *d_assign;           /* [n_frames * n_users] or NULL */
+    int32_t *d_present;          /* [n_frames] or NULL */
+} vet_video;
+int vet_spatial_entropy_batch(vet_plan *plan, int n_videos, const vet_video *videos, int32_t *d_status,
+                              void *stream);
+/* Same with concatenated host buffers (video v starts where video v-1 ends); synchronous. */
+int vet_spatial_entropy_batch_host(vet_plan *plan, int n_videos, const int *n_users, const int *n_frames,
+                                   const double *h_mu, const double *h_mv, double *h_entropy,
+                                   int32_t *h_assign, int32_t *h_present);
+
 /* ---- host-buffer convenience: H2D, run, D2H, synchronous ------------------
  * Return VET_ERR_RANGE / VET_ERR_EMPTY when the status words are non-zero (outputs are still
  * written).  h_mu/h_mv may be NULL when h_ids is given and vice versa. */

@@ -214,3 +214,21 @@ def test_ids_with_several_lattices(native, engine, policy):
     np.testing.assert_allclose(res["entropy"], ref / len(tcs), rtol=1e-8)
     assert np.array_equal(res["present"], (ids >= 0).sum(1))
     plan.close()
+
+
+@pytest.mark.parametrize("policy", [1, -1, 0])
+def test_batch_of_videos_in_one_launch(native, engine, policy):
+    """vet_spatial_entropy_batch: videos of different shapes share one launch (table formulation) or
+    run one by one inside the call (other policies); results equal the per-video calls bit for bit."""
+    shapes = [(8, 30), (64, 100), (33, 7), (300, 12), (1, 5), (64, 100)]
+    vids = [video(u, t, seed=10 * i + u) for i, (u, t) in enumerate(shapes)]
+    plan = plan_for(native, engine, [50, 100], policy=policy)
+    got = plan.spatial_batch(vids, want_assign=True)
+    for (mu, mv), g in zip(vids, got):
+        one = plan.spatial(mu=mu, mv=mv)
+        if policy != 0:                # under 'auto' the formulation may switch between the calls
+            assert np.array_equal(g["entropy"], one["entropy"])
+        assert np.array_equal(g["assign"], one["assign"]) and np.array_equal(g["present"], one["present"])
+        ent, assign, _ = vo.spatial_series(mu, mv, 100, 200, [50, 100])
+        np.testing.assert_allclose(g["entropy"], ent, rtol=1e-8)
+    plan.close()

@@ -61,6 +61,7 @@ struct vet_ctx {
     // grow-only device staging buffers of the host-buffer entry points (no hipMalloc per call)
     void* pool[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t pool_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<vet::VideoDesc> batch_desc;   // host copy of the last batch's descriptors (kept alive)
     // profiling
     bool profiling = false;
     std::vector<EventPair> pending;
@@ -295,6 +296,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         }
         if (ok) {
             vet::LutParams q;
+            q.videos = nullptr; q.n_videos = 0;
             q.src = src; q.U = U; q.T = T;
             q.nearest = pl->lat[0].d_nearest;
             q.K = K; q.n_sum = 0;
@@ -792,6 +794,93 @@ int vet_transition_entropy_ids(vet_plan* pl, const int32_t* d_ids, int U, int T,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Batch of videos in ONE launch (weighted table formulation): short videos are launch-bound one at
+// a time (config 2: 43 us of kernel per call), so their frame blocks share a grid.  Falls back to
+// one call per video when the table formulation does not apply.
+static int pooled(vet_ctx* c, int slot, size_t bytes, void** out);
+
+int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* videos, int32_t* d_status, void* stream) {
+    if (!pl) return fail(VET_ERR_INVALID, "plan is NULL");
+    if (n_videos <= 0 || !videos) return fail(VET_ERR_INVALID, "need at least one video");
+    if (!pl->grid) return fail(VET_ERR_INVALID, "plan has no pixel grid");
+    vet_ctx* c = pl->ctx;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const int K = (int)pl->lat.size();
+    long total = 0;
+    for (int v = 0; v < n_videos; ++v) {
+        const vet_video& x = videos[v];
+        if (x.n_users <= 0 || x.n_frames <= 0 || !x.d_mu || !x.d_mv || !x.d_entropy)
+            return fail(VET_ERR_INVALID, "video %d: bad shape or NULL pointer", v);
+        total += (long)x.n_users * x.n_frames;
+    }
+    bool table = pl->weighted && pl->table_policy >= 0 && !any_binned(pl) && K <= vet::MAX_LATTICES &&
+                 (pl->table_policy > 0 || pl->lat[0].stride > 0 || pl->samples_seen + total >= 16 * (long)pl->n_dirs);
+    if (table)
+        for (int k = 0; k < K && table; ++k) {
+            int rc = ensure_wtab(pl, k, s);
+            if (rc) return rc;
+            table = pl->lat[k].stride > 0;
+        }
+    int n_sum = 0;
+    for (int k = 0; k < K; ++k) n_sum += pl->lat[k].n;
+    std::vector<vet::VideoDesc>& desc = c->batch_desc;
+    size_t lds_max = 0;
+    if (table) {
+        desc.resize(n_videos);
+        int block = 0;
+        for (int v = 0; v < n_videos && table; ++v) {
+            const vet_video& x = videos[v];
+            vet::VideoDesc& d = desc[v];
+            d.mu = x.d_mu; d.mv = x.d_mv; d.U = x.n_users; d.T = x.n_frames;
+            d.entropy = x.d_entropy; d.assign = x.d_assign; d.present = x.d_present;
+            d.UC = d.U < 2048 ? d.U : 2048;
+            int fpw = d.U >= 256 ? 1 : (d.U >= 64 ? 4 : 16);
+            size_t lds = 0;
+            for (;; fpw /= 2) {
+                lds = (size_t)fpw * n_sum * 8 + (size_t)fpw * d.UC * 6 + (size_t)2 * fpw * 4 + 64;
+                if (lds <= c->lds_max || fpw == 1) break;
+            }
+            if (lds > c->lds_max) table = false;
+            d.FPW = fpw; d.block0 = block; d.pad_ = 0;
+            block += (d.T + fpw - 1) / fpw;
+            lds_max = lds > lds_max ? lds : lds_max;
+        }
+        if (table) {
+            void* d_desc = nullptr;
+            int rc = pooled(c, 7, desc.size() * sizeof(vet::VideoDesc), &d_desc);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(vet::VideoDesc), hipMemcpyHostToDevice, s));
+            vet::LutParams q;
+            q.videos = (const vet::VideoDesc*)d_desc; q.n_videos = n_videos;
+            q.src = vet::SampleSrc{nullptr, nullptr, nullptr, pl->W, pl->H, (long)pl->n_dirs};
+            q.U = 0; q.T = 0;
+            q.nearest = pl->lat[0].d_nearest;
+            q.K = K; q.n_sum = n_sum;
+            for (int k = 0; k < K; ++k) {
+                const Lattice& L = pl->lat[k];
+                q.lat[k].tab_w = L.d_tab_w; q.lat[k].tab_i = L.d_tab_i; q.lat[k].tab_len = L.d_tab_len;
+                q.lat[k].stride = L.stride; q.lat[k].gs_log2 = L.stride > 32 ? 4 : 3;
+                q.lat[k].n = L.n; q.lat[k].hmax = L.hmax;
+            }
+            q.entropy = nullptr; q.assign = nullptr; q.weights = nullptr; q.present = nullptr; q.status = d_status;
+            q.FPW = 1; q.UC = 1;
+            pl->samples_seen += total;
+            ProfScope ps(c, s, KID_SPATIAL);
+            hipLaunchKernelGGL((vet::k_spatial_lut<false, 2>), dim3((unsigned)block), dim3(256), lds_max, s, q);
+            HIP_TRY(hipGetLastError());
+            return VET_OK;
+        }
+    }
+    for (int v = 0; v < n_videos; ++v) {
+        const vet_video& x = videos[v];
+        int rc = vet_spatial_entropy(pl, x.d_mu, x.d_mv, x.n_users, x.n_frames, x.d_entropy, x.d_assign, nullptr,
+                                     x.d_present, d_status, s);
+        if (rc) return rc;
+    }
+    return VET_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-buffer variants: stage through the context's grow-only device buffers (synchronous)
 namespace {
 struct DevBuf {
@@ -885,6 +974,55 @@ int vet_transition_entropy_host(vet_plan* pl, const double* h_mu, const double* 
                                 int T, double* h_entropy, int32_t* h_pairs, int32_t* h_srccount,
                                 int32_t* h_common) {
     return run_host(pl, true, h_mu, h_mv, h_ids, U, T, h_entropy, h_pairs, h_srccount, h_common);
+}
+
+// Concatenated host buffers: video v's samples start at element sum_{w<v} U_w*T_w of h_mu / h_mv /
+// h_assign and its entropies at sum_{w<v} T_w of h_entropy / h_present.  Two H2D copies, one launch
+// (when the table formulation applies), two or three D2H copies.
+int vet_spatial_entropy_batch_host(vet_plan* pl, int n_videos, const int* n_users, const int* n_frames,
+                                   const double* h_mu, const double* h_mv, double* h_entropy, int32_t* h_assign,
+                                   int32_t* h_present) {
+    if (!pl || n_videos <= 0 || !n_users || !n_frames || !h_mu || !h_mv || !h_entropy)
+        return fail(VET_ERR_INVALID, "bad batch arguments");
+    vet_ctx* c = pl->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    size_t S = 0, R = 0;
+    for (int v = 0; v < n_videos; ++v) {
+        if (n_users[v] <= 0 || n_frames[v] <= 0) return fail(VET_ERR_INVALID, "video %d: bad shape", v);
+        S += (size_t)n_users[v] * n_frames[v];
+        R += (size_t)n_frames[v];
+    }
+    void *mu = nullptr, *mv = nullptr, *ent = nullptr, *as = nullptr, *pr = nullptr, *st = nullptr;
+    POOL(0, S * 8, mu); POOL(1, S * 8, mv); POOL(2, R * 8, ent);
+    if (h_assign) POOL(3, S * 4, as);
+    if (h_present) POOL(5, R * 4, pr);
+    POOL(6, 8, st);
+    HIP_TRY(hipMemcpyAsync(mu, h_mu, S * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(mv, h_mv, S * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(st, 0, 8, s));
+    std::vector<vet_video> vids(n_videos);
+    size_t so = 0, ro = 0;
+    for (int v = 0; v < n_videos; ++v) {
+        vids[v].d_mu = (const double*)mu + so; vids[v].d_mv = (const double*)mv + so;
+        vids[v].n_users = n_users[v]; vids[v].n_frames = n_frames[v];
+        vids[v].d_entropy = (double*)ent + ro;
+        vids[v].d_assign = as ? (int32_t*)as + so : nullptr;
+        vids[v].d_present = pr ? (int32_t*)pr + ro : nullptr;
+        so += (size_t)n_users[v] * n_frames[v];
+        ro += (size_t)n_frames[v];
+    }
+    int rc = vet_spatial_entropy_batch(pl, n_videos, vids.data(), (int32_t*)st, s);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    int32_t status[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h_entropy, ent, R * 8, hipMemcpyDeviceToHost, s));
+    if (h_assign) HIP_TRY(hipMemcpyAsync(h_assign, as, S * 4, hipMemcpyDeviceToHost, s));
+    if (h_present) HIP_TRY(hipMemcpyAsync(h_present, pr, R * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(status, st, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (status[0]) return fail(VET_ERR_RANGE, "Normalized coordinates must be between 0 and 1 (%d samples)", status[0]);
+    if (status[1]) return fail(VET_ERR_EMPTY, "%d frame(s) without any user (Empty vector dictionary)", status[1]);
+    return VET_OK;
 }
 
 }  // extern "C"

@@ -535,7 +535,21 @@ struct LutLattice {
     double hmax;
 };
 
+// One video of a batched launch (vet_spatial_entropy_batch): many short videos share one grid,
+// workgroups [block0, block0 + ceil(T / FPW)) belong to the video.
+struct VideoDesc {
+    const double* mu;
+    const double* mv;
+    int U, T;
+    double* entropy;
+    int32_t* assign;
+    int32_t* present;
+    int FPW, UC, block0, pad_;
+};
+
 struct LutParams {
+    const VideoDesc* videos;      // null: single video described by the fields below
+    int n_videos;
     SampleSrc src;
     int U, T;
     const uint16_t* nearest;      // lattice 0 (assign)
@@ -556,47 +570,67 @@ struct LutParams {
 template <bool FROM_IDS, int UN>
 __global__ void k_spatial_lut(const LutParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // the video this workgroup works on: the launch's only one, or one of a batch
+    SampleSrc src = p.src;
+    int U = p.U, T = p.T, FPW = p.FPW, UC = p.UC;
+    double* entropy = p.entropy;
+    int32_t* assign = p.assign;
+    int32_t* present = p.present;
+    double* weights = p.weights;
+    long blk = blockIdx.x;
+    if (p.videos) {
+        int lo = 0, hi = p.n_videos - 1;                   // last video with block0 <= blockIdx.x
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (p.videos[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        const VideoDesc& d = p.videos[lo];
+        src.mu = d.mu; src.mv = d.mv;
+        U = d.U; T = d.T; FPW = d.FPW; UC = d.UC;
+        entropy = d.entropy; assign = d.assign; present = d.present; weights = nullptr;
+        blk -= d.block0;
+    }
     unsigned long long* hist = (unsigned long long*)smem;                        // [FPW][n_sum]
-    int* ids = (int*)(hist + (size_t)p.FPW * p.n_sum);                           // [FPW][UC]
-    int* cnt_chunk = ids + (size_t)p.FPW * p.UC;                                 // [FPW]
-    int* cnt_frame = cnt_chunk + p.FPW;                                          // [FPW]
-    uint16_t* lens = (uint16_t*)(cnt_frame + p.FPW);                             // [FPW][UC] row lengths
+    int* ids = (int*)(hist + (size_t)FPW * p.n_sum);                             // [FPW][UC]
+    int* cnt_chunk = ids + (size_t)FPW * UC;                                     // [FPW]
+    int* cnt_frame = cnt_chunk + FPW;                                            // [FPW]
+    uint16_t* lens = (uint16_t*)(cnt_frame + FPW);                               // [FPW][UC] row lengths
     const int NW = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
-    const long f0 = (long)blockIdx.x * p.FPW;
-    const int nf = (int)min((long)p.FPW, (long)p.T - f0);
-    for (int i = tid; i < p.FPW * p.n_sum; i += blockDim.x) hist[i] = 0ull;
-    for (int i = tid; i < 2 * p.FPW; i += blockDim.x) cnt_chunk[i] = 0;
+    const long f0 = blk * FPW;
+    const int nf = (int)min((long)FPW, (long)T - f0);
+    for (int i = tid; i < FPW * p.n_sum; i += blockDim.x) hist[i] = 0ull;
+    for (int i = tid; i < 2 * FPW; i += blockDim.x) cnt_chunk[i] = 0;
     bool bad = false;
-    for (int u0 = 0; u0 < p.U; u0 += p.UC) {
-        const int uc = min(p.UC, p.U - u0);
+    for (int u0 = 0; u0 < U; u0 += UC) {
+        const int uc = min(UC, U - u0);
         __syncthreads();
-        for (int i = tid; i < p.FPW; i += blockDim.x) cnt_chunk[i] = 0;
+        for (int i = tid; i < FPW; i += blockDim.x) cnt_chunk[i] = 0;
         __syncthreads();
         for (int i = tid; i < nf * uc; i += blockDim.x) {
             const int fl = i / uc, uu = i - fl * uc;
-            const long idx = (f0 + fl) * (long)p.U + u0 + uu;
-            const int id = sample_dir<FROM_IDS>(p.src, idx, bad);
-            if (id >= 0) ids[(size_t)fl * p.UC + atomicAdd(&cnt_chunk[fl], 1)] = id;
-            if (p.assign) p.assign[idx] = id >= 0 ? (int)p.nearest[id] : -1;
+            const long idx = (f0 + fl) * (long)U + u0 + uu;
+            const int id = sample_dir<FROM_IDS>(src, idx, bad);
+            if (id >= 0) ids[(size_t)fl * UC + atomicAdd(&cnt_chunk[fl], 1)] = id;
+            if (assign) assign[idx] = id >= 0 ? (int)p.nearest[id] : -1;
         }
         __syncthreads();
-        for (int i = tid; i < p.FPW; i += blockDim.x) cnt_frame[i] += cnt_chunk[i];
+        for (int i = tid; i < FPW; i += blockDim.x) cnt_frame[i] += cnt_chunk[i];
         int hoff = 0;
         for (int k = 0; k < p.K; ++k) {
             const LutLattice& L = p.lat[k];
             // row lengths of this lattice for every staged user: one parallel gather, so the walk
             // below has no dependent global load in front of its row loads
             if (k) __syncthreads();
-            for (int i = tid; i < nf * p.UC; i += blockDim.x) {
-                const int fl = i / p.UC, j = i - fl * p.UC;
+            for (int i = tid; i < nf * UC; i += blockDim.x) {
+                const int fl = i / UC, j = i - fl * UC;
                 if (j < cnt_chunk[fl]) lens[i] = L.tab_len[ids[i]];
             }
             __syncthreads();
             for (int fl = 0; fl < nf; ++fl)
-                walk_rows<UN>(ids + (size_t)fl * p.UC, lens + (size_t)fl * p.UC, cnt_chunk[fl],
+                walk_rows<UN>(ids + (size_t)fl * UC, lens + (size_t)fl * UC, cnt_chunk[fl],
                               hist + (size_t)fl * p.n_sum + hoff, L.tab_w, L.tab_i, L.stride, L.gs_log2,
-                              (long)p.src.n_dirs * L.stride);
+                              (long)src.n_dirs * L.stride);
             hoff += L.n;
         }
     }
@@ -618,7 +652,7 @@ __global__ void k_spatial_lut(const LutParams p) {
                     const double q = (double)v / totd;
                     h -= q * log2(q);
                 }
-                if (k == 0 && p.weights) p.weights[(f0 + fl) * (long)n + t] = (double)v / 4294967296.0;
+                if (k == 0 && weights) weights[(f0 + fl) * (long)n + t] = (double)v / 4294967296.0;
             }
             h = wave_sum(h);
             total_entropy += h / p.lat[k].hmax;
@@ -631,8 +665,8 @@ __global__ void k_spatial_lut(const LutParams p) {
                 e = __builtin_nan("");
                 if (p.status) atomicAdd(&p.status[1], 1);
             }
-            p.entropy[f0 + fl] = e;
-            if (p.present) p.present[f0 + fl] = np;
+            entropy[f0 + fl] = e;
+            if (present) present[f0 + fl] = np;
         }
     }
     if (p.status) {

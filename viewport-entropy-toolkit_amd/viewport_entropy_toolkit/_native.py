@@ -37,6 +37,12 @@ class NativeError(RuntimeError):
         self.code = code
 
 
+class Video(C.Structure):
+    """include/vet.h: vet_video (device pointers of one video of a batch)."""
+    _fields_ = [("d_mu", C.c_void_p), ("d_mv", C.c_void_p), ("n_users", C.c_int), ("n_frames", C.c_int),
+                ("d_entropy", C.c_void_p), ("d_assign", C.c_void_p), ("d_present", C.c_void_p)]
+
+
 class _PlanDesc(C.Structure):
     _fields_ = [
         ("video_width", C.c_int), ("video_height", C.c_int),
@@ -79,6 +85,8 @@ SIGNATURES = {
     "vet_spatial_entropy_ids": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vet_transition_entropy": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vet_transition_entropy_ids": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vet_spatial_entropy_batch": (_I, [_P, _I, _P, _P, _P]),
+    "vet_spatial_entropy_batch_host": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "vet_spatial_entropy_host": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "vet_transition_entropy_host": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
 }
@@ -289,6 +297,35 @@ class Plan:
         if rc not in (VET_OK, VET_ERR_EMPTY, VET_ERR_RANGE) or (check and rc != VET_OK):
             _check(self.lib, rc)
         return dict(entropy=ent, pairs=pairs, srccount=src, common=common, code=rc)
+
+    def spatial_batch(self, videos, want_assign=False, check=True):
+        """Many videos, one launch.  ``videos``: sequence of (mu[T,U], mv[T,U]).  Returns a list of
+        dict(entropy[T], assign[T,U]|None, present[T]) in the same order."""
+        mus = [np.ascontiguousarray(m, dtype=np.float64) for m, _ in videos]
+        mvs = [np.ascontiguousarray(v, dtype=np.float64) for _, v in videos]
+        T = np.asarray([m.shape[0] for m in mus], dtype=np.int32)
+        U = np.asarray([m.shape[1] for m in mus], dtype=np.int32)
+        mu = np.concatenate([m.ravel() for m in mus])
+        mv = np.concatenate([v.ravel() for v in mvs])
+        ent = np.empty(int(T.sum()), dtype=np.float64)
+        present = np.empty(int(T.sum()), dtype=np.int32)
+        assign = np.empty(mu.size, dtype=np.int32) if want_assign else None
+        rc = self.lib.vet_spatial_entropy_batch_host(self.handle, len(mus), _ptr(U), _ptr(T), _ptr(mu), _ptr(mv),
+                                                     _ptr(ent), _ptr(assign), _ptr(present))
+        if rc not in (VET_OK, VET_ERR_EMPTY, VET_ERR_RANGE) or (check and rc != VET_OK):
+            _check(self.lib, rc)
+        out, so, ro = [], 0, 0
+        for t, u in zip(T.tolist(), U.tolist()):
+            out.append(dict(entropy=ent[ro:ro + t], present=present[ro:ro + t],
+                            assign=assign[so:so + t * u].reshape(t, u) if want_assign else None))
+            so += t * u
+            ro += t
+        return out
+
+    def spatial_batch_device(self, videos, d_status: int = 0, stream: int = 0):
+        """``videos``: ctypes array of ``Video`` (device pointers); asynchronous on ``stream``."""
+        _check(self.lib, self.lib.vet_spatial_entropy_batch(self.handle, len(videos), videos, d_status or None,
+                                                            stream or None))
 
     # --- device-pointer runs (inputs resident in HBM; asynchronous on ``stream``) ----
     def spatial_device(self, d_mu: int, d_mv: int, n_users: int, n_frames: int, d_entropy: int, d_assign: int = 0,
