@@ -54,6 +54,13 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
+// Workgroup barrier for LDS-only hand-offs: waits for this wave's LDS operations (lgkmcnt), not for
+// its global loads/stores, so requests to HBM stay in flight across it (__syncthreads() also
+// drains vmcnt).  Only for phases that exchange data through LDS.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // numpy-scalar round(v, 6) == rint(v * 1e6) / 1e6   (data_types.py:213-215)
 __device__ __forceinline__ double round6(double v) { return rint(v * 1e6) / 1e6; }
 
@@ -825,33 +832,61 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
     const int ipf = PAIRS ? p.U >> 1 : p.U;                                      // items (pairs or users) per frame
     const float inv_ipf = 1.0f / (float)ipf;
     const long nblocks = ((long)p.T + FB - 1) / FB;
+    // PAIRS: the next round's samples are requested before the barriers of this round (the barriers
+    // wait for LDS traffic only, see lds_barrier), so HBM loads stay in flight while the waves
+    // reduce the round's histograms.
+    double2 a[PPT], b[PPT];
+    if (PAIRS && (long)blockIdx.x < nblocks) {
+        const long f0 = (long)blockIdx.x * FB;
+        const int nitems = (int)min((long)FB, (long)p.T - f0) * ipf;
+        const double2* mu2 = (const double2*)(p.src.mu + f0 * (long)p.U);
+        const double2* mv2 = (const double2*)(p.src.mv + f0 * (long)p.U);
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = tid + k * (int)blockDim.x;
+            if (i < nitems) { a[k] = mu2[i]; b[k] = mv2[i]; }
+        }
+    }
     for (long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         const long f0 = blk * FB;
         const int nf = (int)min((long)FB, (long)p.T - f0);
         const int nitems = nf * ipf;
         if (PAIRS) {
-            const double2* mu2 = (const double2*)(p.src.mu + f0 * (long)p.U);
-            const double2* mv2 = (const double2*)(p.src.mv + f0 * (long)p.U);
             int2* out2 = (int2*)(p.assign ? p.assign + f0 * (long)p.U : nullptr);
-            double2 a[PPT], b[PPT];
+            int near[PPT][2];
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 const int i = tid + k * (int)blockDim.x;
-                if (i < nitems) { a[k] = mu2[i]; b[k] = mv2[i]; }
+                near[k][0] = near[k][1] = -1;
+                if (i < nitems) {
+                    const int id0 = grid_dir(a[k].x, b[k].x, p.src.W, p.src.H, bad);
+                    const int id1 = grid_dir(a[k].y, b[k].y, p.src.W, p.src.H, bad);
+                    if (id0 >= 0) near[k][0] = (int)lut[id0];
+                    if (id1 >= 0) near[k][1] = (int)lut[id1];
+                }
+            }
+            // next round's loads go out ahead of this round's stores
+            const long nb = blk + gridDim.x;
+            if (nb < nblocks) {
+                const long g0 = nb * FB;
+                const int nnext = (int)min((long)FB, (long)p.T - g0) * ipf;
+                const double2* mu2 = (const double2*)(p.src.mu + g0 * (long)p.U);
+                const double2* mv2 = (const double2*)(p.src.mv + g0 * (long)p.U);
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const int i = tid + k * (int)blockDim.x;
+                    if (i < nnext) { a[k] = mu2[i]; b[k] = mv2[i]; }
+                }
             }
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 const int i = tid + k * (int)blockDim.x;
                 if (i < nitems) {
                     const int fl = (int)(((float)i + 0.5f) * inv_ipf);           // exact: i < 2^12
-                    const int id0 = grid_dir(a[k].x, b[k].x, p.src.W, p.src.H, bad);
-                    const int id1 = grid_dir(a[k].y, b[k].y, p.src.W, p.src.H, bad);
-                    const int n0 = id0 >= 0 ? (int)lut[id0] : -1;
-                    const int n1 = id1 >= 0 ? (int)lut[id1] : -1;
                     unsigned* row = cnt + (size_t)fl * p.n;
-                    if (n0 >= 0) atomicAdd(&row[n0], 1u);
-                    if (n1 >= 0) atomicAdd(&row[n1], 1u);
-                    if (out2) out2[i] = make_int2(n0, n1);
+                    if (near[k][0] >= 0) atomicAdd(&row[near[k][0]], 1u);
+                    if (near[k][1] >= 0) atomicAdd(&row[near[k][1]], 1u);
+                    if (out2) out2[i] = make_int2(near[k][0], near[k][1]);
                 }
             }
         } else {
@@ -876,7 +911,7 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         // entropy (entropy_utils.py:194-211): wave f reduces frame f and clears its histogram
         for (int f = wv; f < nf; f += NW) {
             unsigned* row = cnt + (size_t)f * p.n;
@@ -905,7 +940,7 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
                 if (p.present) p.present[f0 + f] = np;
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (p.status) {
         const unsigned long long anybad = __ballot(bad);
