@@ -302,6 +302,22 @@ def main():
             "formulation": formulation,
             "plan_build_ms": plan_ms,
         }
+        # besides the HBM figure, say what the run formulation is really bound by
+        if mode == "spatial" and weighted and k_n:
+            n_lat = [2 * (tc // 2) + 1 for tc in tcs]
+            cap = (1.0 - np.cos(np.radians(120.0 / 2.0))) / 2.0          # share of tiles inside the FoV cap
+            if plan.table_stride(0) > 0:
+                gathered = 6.0 * cap * sum(n_lat) * U * T * n_batch / launches_per_step
+                out["roofline"]["secondary"] = {
+                    "bound": "cache-hierarchy row gather (6 B per in-FoV tile and sample, estimated from the cap area)",
+                    "gathered_bytes_per_launch": gathered,
+                    "achieved": gathered / (avg_kernel_ms * 1e-3) / 1e9 / 256.0, "unit": "GB/s per CU",
+                    "guide_rates": {"xcd_l2": [66, 73], "infinity_cache": 33.5, "hbm": [23, 24]}}
+            else:
+                flop = 13.5 * sum(n_lat) * U * T * n_batch / launches_per_step
+                out["roofline"]["secondary"] = {
+                    "bound": "fp64 valu (13.5 flop per tile and sample, SURVEY.md 8d)", "flop_per_launch": flop,
+                    "achieved": flop / (avg_kernel_ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mu_h, mv_h, tcs, mode, weighted, args.cpu_seconds)
         print(json.dumps(out), flush=True)
