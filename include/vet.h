@@ -189,6 +189,24 @@ int vet_transition_entropy_host(vet_plan *plan, const double *h_mu, const double
                                 double *h_entropy, int32_t *h_pairs, int32_t *h_srccount,
                                 int32_t *h_common);
 
+/* ---- host-side track loader (no GPU involved) -------------------------------------------
+ * Replaces the per-file `pd.read_csv(filepath)` + column selection of process_viewport_data
+ * (utilities/data_utils.py:305-316) for a whole directory: the files are parsed on n_threads host
+ * threads (0 = all cores) into FP64 columns `time`, `2dmu`, `2dmv`, one entry per data row, NaN for
+ * a missing value (rows are NOT dropped here; the caller applies dropna and the range checks).
+ * The decimal conversion reproduces pandas' default C-engine converter bit for bit; a file that is
+ * not plain unquoted numeric CSV gets status VET_CSV_FALLBACK and must be parsed by pandas. */
+#define VET_CSV_OK 0
+#define VET_CSV_FALLBACK 1   /* syntax outside the fast path: parse this file with pandas */
+#define VET_CSV_IO 2         /* cannot open / read */
+typedef struct vet_track {
+    double *time, *mu, *mv;  /* malloc'ed by the library, n_rows each; release with vet_csv_free_tracks */
+    int64_t n_rows;
+    int status;              /* VET_CSV_* */
+} vet_track;
+int vet_csv_read_tracks(int n_files, const char *const *paths, vet_track *tracks, int n_threads);
+void vet_csv_free_tracks(int n_files, vet_track *tracks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,8 @@ directions and tiles happens on the device.
 from __future__ import annotations
 
 from pathlib import Path
+import logging
+import os
 from typing import List, Sequence, Tuple, Union
 
 import numpy as np
@@ -42,23 +44,95 @@ def to_pixels(normalized: np.ndarray, dimension: int) -> np.ndarray:
     return (normalized * dimension).astype(int)
 
 
-def read_track(filepath: Union[str, Path], width: int, height: int) -> Tuple[pd.DataFrame, str]:
-    """One user's CSV -> cleaned DataFrame (time, 2dmu, 2dmv, pixel_x, pixel_y, lon, lat)."""
+def _clean(time, mu, mv, labels, filepath: Path, width: int, height: int):
+    """dropna, time shift, range and dimension checks of process_viewport_data (data_utils.py:318-331)."""
+    keep = ~(np.isnan(time) | np.isnan(mu) | np.isnan(mv))
+    if not keep.all():
+        labels, time, mu, mv = labels[keep], time[keep], mu[keep], mv[keep]
+    if len(time) == 0:
+        raise ValidationError(f"No valid data found in {filepath}")
+    time = time - time.min()
+    to_pixels(mu, width)                # range / dimension checks, in the reference's order
+    to_pixels(mv, height)
+    check_video_dimensions(width, height)
+    return labels, time, mu, mv, filepath.stem
+
+
+def _read_columns_pandas(filepath: Path):
+    data = pd.read_csv(filepath, usecols=["time", "2dmu", "2dmv"])
+    return (data["time"].to_numpy(dtype=np.float64), data["2dmu"].to_numpy(dtype=np.float64),
+            data["2dmv"].to_numpy(dtype=np.float64), data.index.to_numpy())
+
+
+def read_samples(filepath: Union[str, Path], width: int, height: int, columns=None):
+    """One user's CSV -> ``(row labels, time, mu, mv, identifier)`` float64 arrays, cleaned and
+    validated as ``process_viewport_data`` does (data_utils.py:289-342: NaN rows dropped, time
+    shifted to start at 0, coordinates checked against [0, 1], dimensions checked) — without
+    building the per-row DataFrame columns the engine never reads.  ``columns`` = raw
+    ``(time, mu, mv)`` already parsed by the native loader."""
     try:
         filepath = Path(filepath)
-        if not filepath.exists():
-            raise FileNotFoundError(f"File not found: {filepath}")
-        data = pd.read_csv(filepath, usecols=["time", "2dmu", "2dmv"]).dropna()
-        if data.empty:
-            raise ValidationError(f"No valid data found in {filepath}")
-        data["time"] -= data["time"].min()
-        data["pixel_x"] = to_pixels(data["2dmu"].values, width)
-        data["pixel_y"] = to_pixels(data["2dmv"].values, height)
-        check_video_dimensions(width, height)
-        data["lon"] = (data["pixel_x"].to_numpy() / width) * 360 - 180
-        data["lat"] = 90 - (data["pixel_y"].to_numpy() / height) * 180
-        return data, filepath.stem
+        if columns is None:
+            if not filepath.exists():
+                raise FileNotFoundError(f"File not found: {filepath}")
+            time, mu, mv, labels = _read_columns_pandas(filepath)
+        else:
+            time, mu, mv = columns
+            labels = np.arange(len(time))
+        return _clean(time, mu, mv, labels, filepath, width, height)
     except Exception as e:  # noqa: BLE001 - the reference funnels every failure into ValidationError
+        raise ValidationError(f"Error processing viewport data: {str(e)}")
+
+
+def read_directory(files: Sequence[Path], width: int, height: int, threads: int = 0):
+    """All user files of one video -> list of ``read_samples`` results, in ``files`` order.
+
+    ``VET_CSV_PARSER`` = ``native`` (default when libvet_hip.so is built): the C-ABI's threaded
+    loader (vet_csv_read_tracks) parses the plain numeric files, pandas the ones it declines, and
+    the first file is parsed both ways and compared, so a pandas whose converter differs sends the
+    whole directory through pandas; ``pandas``: ``pd.read_csv`` for every file, as the reference."""
+    files = [Path(f) for f in files]
+    mode = os.environ.get("VET_CSV_PARSER", "native")
+    parsed = None
+    if mode != "pandas" and files:
+        try:
+            from . import _native
+            parsed = _native.read_tracks(files, threads)
+        except Exception:  # noqa: BLE001 - library not built: the reference's own parser does the job
+            parsed = None
+        if parsed is not None:
+            first = next((i for i, p in enumerate(parsed) if p[0] == 0), None)
+            if first is not None:
+                try:
+                    t, a, b, _ = _read_columns_pandas(files[first])
+                    same = all(np.array_equal(x, y, equal_nan=True) for x, y in zip((t, a, b), parsed[first][1:]))
+                except Exception:  # noqa: BLE001
+                    same = False
+                if not same:
+                    logging.getLogger(__name__).warning("native CSV loader disagrees with pandas on %s; using pandas",
+                                                        files[first])
+                    parsed = None
+    out = []
+    for i, fp in enumerate(files):
+        cols = parsed[i][1:] if parsed is not None and parsed[i][0] == 0 else None
+        out.append(read_samples(fp, width, height, columns=cols))
+    return out
+
+
+def frame_of_samples(labels, time, mu, mv, width: int, height: int) -> pd.DataFrame:
+    """The reference's per-user frame (time, 2dmu, 2dmv, pixel_x, pixel_y, lon, lat) from cleaned samples."""
+    px, py = to_pixels(mu, width), to_pixels(mv, height)
+    return pd.DataFrame({"time": time, "2dmu": mu, "2dmv": mv, "pixel_x": px, "pixel_y": py,
+                         "lon": (px / width) * 360 - 180, "lat": 90 - (py / height) * 180},
+                        index=pd.Index(labels))
+
+
+def read_track(filepath: Union[str, Path], width: int, height: int) -> Tuple[pd.DataFrame, str]:
+    """One user's CSV -> cleaned DataFrame (time, 2dmu, 2dmv, pixel_x, pixel_y, lon, lat)."""
+    labels, time, mu, mv, identifier = read_samples(filepath, width, height)
+    try:
+        return frame_of_samples(labels, time, mu, mv, width, height), identifier
+    except Exception as e:  # noqa: BLE001
         raise ValidationError(f"Error processing viewport data: {str(e)}")
 
 

@@ -43,6 +43,15 @@ class Video(C.Structure):
                 ("d_entropy", C.c_void_p), ("d_assign", C.c_void_p), ("d_present", C.c_void_p)]
 
 
+class Track(C.Structure):
+    """include/vet.h: vet_track (one parsed CSV file, host memory owned by the library)."""
+    _fields_ = [("time", C.POINTER(C.c_double)), ("mu", C.POINTER(C.c_double)), ("mv", C.POINTER(C.c_double)),
+                ("n_rows", C.c_int64), ("status", C.c_int)]
+
+
+VET_CSV_OK, VET_CSV_FALLBACK, VET_CSV_IO = 0, 1, 2
+
+
 class _PlanDesc(C.Structure):
     _fields_ = [
         ("video_width", C.c_int), ("video_height", C.c_int),
@@ -89,6 +98,8 @@ SIGNATURES = {
     "vet_spatial_entropy_batch_host": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "vet_spatial_entropy_host": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "vet_transition_entropy_host": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "vet_csv_read_tracks": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(Track), _I]),
+    "vet_csv_free_tracks": (None, [_I, C.POINTER(Track)]),
 }
 
 _lib = None
@@ -115,6 +126,33 @@ def load_library():
             fn.restype, fn.argtypes = res, args
         _lib = lib
         return lib
+
+
+def read_tracks(paths: Sequence, n_threads: int = 0):
+    """vet_csv_read_tracks over ``paths``: list of ``(status, time, mu, mv)`` with one FP64 entry per
+    data row (NaN = missing); arrays are ``None`` unless status is VET_CSV_OK.  Host code only."""
+    lib = load_library()
+    n = len(paths)
+    if n == 0:
+        return []
+    c_paths = (C.c_char_p * n)(*[os.fsencode(str(p)) for p in paths])
+    tracks = (Track * n)()
+    rc = lib.vet_csv_read_tracks(n, c_paths, tracks, int(n_threads))
+    if rc != VET_OK:
+        raise NativeError(rc, "vet_csv_read_tracks failed")
+    try:
+        out = []
+        for t in tracks:
+            if t.status == VET_CSV_OK:
+                m = int(t.n_rows)
+                cols = [np.frombuffer(C.string_at(ptr, m * 8), dtype=np.float64).copy() if m else np.empty(0)
+                        for ptr in (t.time, t.mu, t.mv)]
+                out.append((VET_CSV_OK, *cols))
+            else:
+                out.append((int(t.status), None, None, None))
+        return out
+    finally:
+        lib.vet_csv_free_tracks(n, tracks)
 
 
 def _check(lib, rc: int):

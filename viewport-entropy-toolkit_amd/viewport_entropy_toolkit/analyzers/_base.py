@@ -11,7 +11,6 @@ from __future__ import annotations
 import logging
 import os
 import time
-from concurrent.futures import ThreadPoolExecutor
 from datetime import datetime
 from pathlib import Path
 from typing import Dict, List, Optional
@@ -27,17 +26,23 @@ from ..utilities.visualization_utils import save_graph
 
 
 class _DataCache(dict):
-    """``{'points', 'vectors', 'trajectory_data'}`` with the two object DataFrames built on
-    first access (the engine itself only needs the dense arrays)."""
+    """``{'trajectory_data', 'points', 'vectors'}`` of the reference, every entry built on first
+    access from the cleaned samples (the engine itself only needs the dense arrays)."""
 
-    def __init__(self, trajectory_data):
-        super().__init__(trajectory_data=trajectory_data)
-        self._lazy = {"points", "vectors"}
+    def __init__(self, samples, width, height):
+        super().__init__()
+        self._samples, self._dims = samples, (width, height)
+        self._lazy = {"trajectory_data", "points", "vectors"}
         self.user_vectors = False
 
-    def _fill(self):
-        if self._lazy:
-            self._lazy = set()
+    def _fill(self, key):
+        if "trajectory_data" in self._lazy:
+            self._lazy.discard("trajectory_data")
+            dict.__setitem__(self, "trajectory_data",
+                             [(name, _ingest.frame_of_samples(labels, t, a, b, *self._dims))
+                              for labels, t, a, b, name in self._samples])
+        if key != "trajectory_data" and key in self._lazy:
+            self._lazy -= {"points", "vectors"}
             copies = [(name, df.copy()) for name, df in dict.__getitem__(self, "trajectory_data")]
             points, vectors = format_trajectory_data(copies)
             dict.__setitem__(self, "points", points)
@@ -45,7 +50,7 @@ class _DataCache(dict):
 
     def __getitem__(self, key):
         if key in self._lazy:
-            self._fill()
+            self._fill(key)
         return dict.__getitem__(self, key)
 
     def __setitem__(self, key, value):
@@ -62,6 +67,9 @@ class _DataCache(dict):
 
     def __contains__(self, key):
         return key in self._lazy or dict.__contains__(self, key)
+
+    def __bool__(self):
+        return True
 
     def keys(self):
         return list(dict.keys(self)) + sorted(self._lazy)
@@ -92,16 +100,10 @@ class _EntropyAnalyzerBase:
         t_start = time.perf_counter()
         try:
             files = list(directory.glob("*.csv"))          # glob order = user (column) order, as in the reference
-            read = lambda fp: _ingest.read_track(fp, self.config.video_width, self.config.video_height)  # noqa: E731
-            if len(files) > 16:                              # CSV parsing releases the GIL: overlap the files
-                with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
-                    parsed = list(pool.map(read, files))
-            else:
-                parsed = [read(fp) for fp in files]
-            trajectory_data = [(identifier, data) for data, identifier in parsed]
-            times, mu, mv = _ingest.build_dense(_ingest.tracks_from_frames(trajectory_data))
-            self._dense = (times, mu, mv, [name for name, _ in trajectory_data])
-            self._data_cache = _DataCache(trajectory_data)
+            samples = _ingest.read_directory(files, self.config.video_width, self.config.video_height)
+            times, mu, mv = _ingest.build_dense([(t, a, b) for _, t, a, b, _ in samples])
+            self._dense = (times, mu, mv, [name for *_, name in samples])
+            self._data_cache = _DataCache(samples, self.config.video_width, self.config.video_height)
             self._entropy_results = None
             self.last_timing = {"ingest_s": time.perf_counter() - t_start}
         except Exception as e:  # noqa: BLE001
