@@ -81,6 +81,8 @@ struct Lattice {
     uint16_t* d_tab_i = nullptr;   // [n_dirs][stride]
     uint16_t* d_tab_len = nullptr; // [n_dirs]
     int stride = 0;                // 0 = not built, -1 = not usable (too large)
+    int gs_log2 = 4;               // lanes per gather group (log2); fixed when the table is built
+    bool interleaved = false;      // row entries dealt round-robin over the group's lanes (slot_of)
     bool binned = false;           // caller-supplied direction -> bin table (naive lat/lon tiling)
     int norm_n = 0;                // tile count used by the normaliser rule
 };
@@ -231,7 +233,7 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     p.tiles = L.d_tiles; p.n = L.n;
     p.cos_cull = pl->cos_cull;
     p.wc.max_ang = pl->max_ang; p.wc.inv_max = 1.0 / pl->max_ang; p.wc.power = pl->power; p.wc.shift = 0;
-    p.stride = 0; p.w = nullptr; p.idx = nullptr; p.len = nullptr; p.maxcount = d_max;
+    p.stride = 0; p.w = nullptr; p.idx = nullptr; p.len = nullptr; p.maxcount = d_max; p.gs_log2 = -1;
     const int blocks = grid_for((long)pl->n_dirs * vet::WAVE, 256, c->n_cu * 2);
     {
         ProfScope ps(c, s, KID_WTAB);
@@ -251,7 +253,15 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     HIP_TRY(hipMalloc((void**)&L.d_tab_w, (size_t)(pl->n_dirs + 1) * stride * 4));
     HIP_TRY(hipMalloc((void**)&L.d_tab_i, (size_t)(pl->n_dirs + 1) * stride * 2));
     HIP_TRY(hipMalloc((void**)&L.d_tab_len, (size_t)(pl->n_dirs + 1) * 2));
+    // 4 entries per lane; 16-lane groups and 2 rows in flight per group measured best
+    // (profiles/r01/v4_table_vs_xcd_partition_sweep.log); the group size is part of the row layout
+    L.gs_log2 = stride > 32 ? 4 : 3;
+    if (const char* e = getenv("VET_GS_LOG2")) L.gs_log2 = atoi(e);
+    // rows longer than one block only: short rows (small lattices) keep the leaner plain walk
+    L.interleaved = stride % (4 << L.gs_log2) == 0 && stride > (4 << L.gs_log2);
+    if (const char* e = getenv("VET_TAB_INTERLEAVE")) L.interleaved = L.interleaved && atoi(e) != 0;
     p.stride = stride; p.w = L.d_tab_w; p.idx = L.d_tab_i; p.len = L.d_tab_len; p.maxcount = nullptr;
+    p.gs_log2 = L.interleaved ? L.gs_log2 : -1;
     {
         ProfScope ps(c, s, KID_WTAB);
         hipLaunchKernelGGL(vet::k_wtab<true>, dim3(blocks), dim3(256), 0, s, p);
@@ -304,10 +314,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
                 const Lattice& L = pl->lat[k];
                 q.lat[k].tab_w = L.d_tab_w; q.lat[k].tab_i = L.d_tab_i; q.lat[k].tab_len = L.d_tab_len;
                 q.lat[k].stride = L.stride;
-                // 4 entries per lane; 16-lane groups and 2 rows in flight per group measured best
-                // (profiles/r01/v4_table_vs_xcd_partition_sweep.log)
-                q.lat[k].gs_log2 = L.stride > 32 ? 4 : 3;
-                if (const char* e = getenv("VET_GS_LOG2")) q.lat[k].gs_log2 = atoi(e);
+                q.lat[k].gs_log2 = L.gs_log2; q.lat[k].interleaved = L.interleaved ? 1 : 0;
                 q.lat[k].n = L.n; q.lat[k].hmax = L.hmax;
                 q.n_sum += L.n;
             }
@@ -324,14 +331,14 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
             if (lds <= c->lds_max) {
                 q.FPW = fpw;
                 const int blocks = (T + fpw - 1) / fpw;
-                int un = 2;
-                if (const char* e = getenv("VET_UN")) un = atoi(e);
                 int threads = 256;
                 if (const char* e = getenv("VET_LUT_THREADS")) threads = atoi(e);
+                bool il = false;
+                for (int k = 0; k < K; ++k) il = il || pl->lat[k].interleaved;
                 ProfScope ps(c, s, KID_SPATIAL);
-                if (un == 8) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 8>), dim3(blocks), dim3(threads), lds, s, q);
-                else if (un == 4) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 4>), dim3(blocks), dim3(threads), lds, s, q);
-                else hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2>), dim3(blocks), dim3(threads), lds, s, q);
+                // 2 rows in flight per lane group measured best (4 and 8 were tried, profiles/r01/v3_*)
+                if (il) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2, true>), dim3(blocks), dim3(threads), lds, s, q);
+                else hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2, false>), dim3(blocks), dim3(threads), lds, s, q);
                 HIP_TRY(hipGetLastError());
                 return VET_OK;
             }
@@ -688,8 +695,10 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
             PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<false>(wm, R), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
             PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<true>(wm, R), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
         }
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
@@ -859,14 +868,17 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
             for (int k = 0; k < K; ++k) {
                 const Lattice& L = pl->lat[k];
                 q.lat[k].tab_w = L.d_tab_w; q.lat[k].tab_i = L.d_tab_i; q.lat[k].tab_len = L.d_tab_len;
-                q.lat[k].stride = L.stride; q.lat[k].gs_log2 = L.stride > 32 ? 4 : 3;
+                q.lat[k].stride = L.stride; q.lat[k].gs_log2 = L.gs_log2; q.lat[k].interleaved = L.interleaved ? 1 : 0;
                 q.lat[k].n = L.n; q.lat[k].hmax = L.hmax;
             }
             q.entropy = nullptr; q.assign = nullptr; q.weights = nullptr; q.present = nullptr; q.status = d_status;
             q.FPW = 1; q.UC = 1;
             pl->samples_seen += total;
             ProfScope ps(c, s, KID_SPATIAL);
-            hipLaunchKernelGGL((vet::k_spatial_lut<false, 2>), dim3((unsigned)block), dim3(256), lds_max, s, q);
+            bool il = false;
+            for (int k = 0; k < K; ++k) il = il || pl->lat[k].interleaved;
+            if (il) hipLaunchKernelGGL((vet::k_spatial_lut<false, 2, true>), dim3((unsigned)block), dim3(256), lds_max, s, q);
+            else hipLaunchKernelGGL((vet::k_spatial_lut<false, 2, false>), dim3((unsigned)block), dim3(256), lds_max, s, q);
             HIP_TRY(hipGetLastError());
             return VET_OK;
         }
