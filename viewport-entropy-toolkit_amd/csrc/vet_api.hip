@@ -253,12 +253,15 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     HIP_TRY(hipMalloc((void**)&L.d_tab_w, (size_t)(pl->n_dirs + 1) * stride * 4));
     HIP_TRY(hipMalloc((void**)&L.d_tab_i, (size_t)(pl->n_dirs + 1) * stride * 2));
     HIP_TRY(hipMalloc((void**)&L.d_tab_len, (size_t)(pl->n_dirs + 1) * 2));
-    // 4 entries per lane; 16-lane groups and 2 rows in flight per group measured best
-    // (profiles/r01/v4_table_vs_xcd_partition_sweep.log); the group size is part of the row layout
-    L.gs_log2 = stride > 32 ? 4 : 3;
+    // 4 entries per lane and 2 rows in flight per group; lanes per row (part of the row layout) = the
+    // smallest power of two whose 4-entry chunks cover the longest row, at most 16 (measured best for
+    // long rows, profiles/r01/v4_table_vs_xcd_partition_sweep.log), so the short rows of small
+    // lattices do not idle most of a group
+    L.gs_log2 = 1;
+    while (L.gs_log2 < 4 && (4 << L.gs_log2) < longest) ++L.gs_log2;
     if (const char* e = getenv("VET_GS_LOG2")) L.gs_log2 = atoi(e);
     // rows longer than one block only: short rows (small lattices) keep the leaner plain walk
-    L.interleaved = stride % (4 << L.gs_log2) == 0 && stride > (4 << L.gs_log2);
+    L.interleaved = stride % (4 << L.gs_log2) == 0 && longest > (4 << L.gs_log2);
     if (const char* e = getenv("VET_TAB_INTERLEAVE")) L.interleaved = L.interleaved && atoi(e) != 0;
     p.stride = stride; p.w = L.d_tab_w; p.idx = L.d_tab_i; p.len = L.d_tab_len; p.maxcount = nullptr;
     p.gs_log2 = L.interleaved ? L.gs_log2 : -1;
@@ -269,6 +272,20 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     HIP_TRY(hipGetLastError());
     L.stride = stride;
     return VET_OK;
+}
+
+// Frames per workgroup of the table kernel: about 1024 samples per workgroup, at most one frame per
+// wave (the epilogue reduces a frame per wave, and every frame costs n_sum * 8 B of LDS), and never
+// so many that the launch has fewer than ~4 workgroups per CU (measured: config 4 best at 4 frames
+// x 256 users, config 2 at 2 x 64 with only 3000 frames; profiles/r01/v6_table_geometry_sweep.log).
+int lut_frames_per_wg(int U, long total_frames, int n_cu) {
+    long f = 1024 / (U > 0 ? U : 1);
+    const long by_grid = total_frames / (4L * n_cu);
+    if (f > by_grid) f = by_grid;
+    if (f > 4) f = 4;
+    int fpw = 1;
+    while (2 * fpw <= f) fpw *= 2;
+    return fpw;
 }
 
 bool any_binned(const vet_plan* pl) {
@@ -320,9 +337,9 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
             }
             q.entropy = d_entropy; q.assign = d_assign; q.weights = d_weights; q.present = d_present;
             q.status = d_status;
-            // geometry: enough frames per workgroup to give every wave >= 8 users
             q.UC = U < 2048 ? U : 2048;
-            int fpw = U >= 256 ? 1 : (U >= 64 ? 4 : 16);
+            int fpw = lut_frames_per_wg(U, T, c->n_cu);
+            if (const char* e = getenv("VET_LUT_FPW")) fpw = atoi(e) > 0 ? atoi(e) : fpw;
             size_t lds = 0;
             for (;; fpw /= 2) {
                 lds = (size_t)fpw * q.n_sum * 8 + (size_t)fpw * q.UC * 6 + (size_t)2 * fpw * 4 + 64;
@@ -815,12 +832,13 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
     vet_ctx* c = pl->ctx;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const int K = (int)pl->lat.size();
-    long total = 0;
+    long total = 0, total_frames = 0;
     for (int v = 0; v < n_videos; ++v) {
         const vet_video& x = videos[v];
         if (x.n_users <= 0 || x.n_frames <= 0 || !x.d_mu || !x.d_mv || !x.d_entropy)
             return fail(VET_ERR_INVALID, "video %d: bad shape or NULL pointer", v);
         total += (long)x.n_users * x.n_frames;
+        total_frames += x.n_frames;
     }
     bool table = pl->weighted && pl->table_policy >= 0 && !any_binned(pl) && K <= vet::MAX_LATTICES &&
                  (pl->table_policy > 0 || pl->lat[0].stride > 0 || pl->samples_seen + total >= 16 * (long)pl->n_dirs);
@@ -843,7 +861,7 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
             d.mu = x.d_mu; d.mv = x.d_mv; d.U = x.n_users; d.T = x.n_frames;
             d.entropy = x.d_entropy; d.assign = x.d_assign; d.present = x.d_present;
             d.UC = d.U < 2048 ? d.U : 2048;
-            int fpw = d.U >= 256 ? 1 : (d.U >= 64 ? 4 : 16);
+            int fpw = lut_frames_per_wg(d.U, total_frames, c->n_cu);
             size_t lds = 0;
             for (;; fpw /= 2) {
                 lds = (size_t)fpw * n_sum * 8 + (size_t)fpw * d.UC * 6 + (size_t)2 * fpw * 4 + 64;
