@@ -260,8 +260,8 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     L.gs_log2 = 1;
     while (L.gs_log2 < 4 && (4 << L.gs_log2) < longest) ++L.gs_log2;
     if (const char* e = getenv("VET_GS_LOG2")) L.gs_log2 = atoi(e);
-    // rows longer than one block only: short rows (small lattices) keep the leaner plain walk
-    L.interleaved = stride % (4 << L.gs_log2) == 0 && longest > (4 << L.gs_log2);
+    // 16-lane rows with at least one block that is 3/4 full get the class-dealt layout (k_wtab)
+    L.interleaved = L.gs_log2 == 4 && stride % 64 == 0 && 4 * longest >= 3 * 64;
     if (const char* e = getenv("VET_TAB_INTERLEAVE")) L.interleaved = L.interleaved && atoi(e) != 0;
     p.stride = stride; p.w = L.d_tab_w; p.idx = L.d_tab_i; p.len = L.d_tab_len; p.maxcount = nullptr;
     p.gs_log2 = L.interleaved ? L.gs_log2 : -1;

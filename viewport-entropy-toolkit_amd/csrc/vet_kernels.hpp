@@ -415,18 +415,26 @@ struct WtabParams {
 };
 
 // Row layout.  The gather gives every lane of a group of GS = 2^gs_log2 lanes one 16-byte chunk
-// (4 slots) per block of B = 4*GS entries.  In a block that is at least 3/4 full the tile-sorted
-// entries are dealt round-robin over the lanes — entry j of the block sits in lane j % GS,
-// component j / GS — so one ds_add_u64 instruction of the group adds GS CONSECUTIVE sorted entries
-// instead of every fourth one, which spreads them over more LDS banks (simulated conflict depth
-// 5.1 -> 4.1 at n = 501; config 3: 1.76 -> 1.67 ms).  Emptier blocks (short rows of small lattices,
-// row tails) keep the plain order, where only the first lanes of the group have work.
+// (4 slots = 4 components) per block of B = 4*GS entries, and component k of all lanes is added by
+// ONE ds_add_u64 instruction.  Measured on MI355X (tools/lds_atomic_probe.hip): the LDS services
+// that instruction in four groups of 16 contiguous lanes, one cycle per group when the 16 slots
+// differ mod 16 (8-byte slots: bank pair = slot mod 16), one more cycle per extra slot of a class,
+// two per extra lane on the same address; lanes of different groups never conflict.  With 16-lane
+// gather groups a hardware group is exactly one row, so the cost is decided by the row layout:
+// tile-sorted entries dealt 4 per lane put tiles ~14 apart into one instruction (mostly one or two
+// classes: ~4 cycles per group).  So in a block that is at least 3/4 full (B = 64, GS = 16) the
+// entries are DEALT BY CLASS: the r-th entry of a class (tile mod 16) goes to component r mod 4,
+// inside a component to the next free lane; what does not fit (a component's 17th entry) and the
+// block's padding fill the remaining (lane, component) places, padding on tiles of classes the
+// component does not use.  Typical result: one entry per class and component = conflict-free.
+// Emptier blocks (short rows of small lattices, row tails) keep the plain order, where only the
+// first lanes of the group have work.
 __device__ __forceinline__ bool block_interleaved(int len, int eb, int gs_log2) {
     const int B = 4 << gs_log2;
     return gs_log2 >= 0 && 4 * min(B, len - eb) >= 3 * B;
 }
-__device__ __forceinline__ int interleaved_slot(int j, int gs_log2) {       // j = entry index inside its block
-    return ((j & ((1 << gs_log2) - 1)) << 2) | (j >> gs_log2);
+__device__ __forceinline__ int below(unsigned long long m) {      // set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
 template <bool FILL>
@@ -472,20 +480,53 @@ __global__ void k_wtab(const WtabParams p) {
                 p.idx[d * p.stride + pos] = (uint16_t)(pos % p.n);
             }
             if (lane == 0) p.len[d] = (uint16_t)count;
-            // well-filled blocks: deal the entries over the gather group's lanes (B <= 64 = one wave pass;
-            // the loads of all lanes have returned before the first store issues)
-            if (p.gs_log2 >= 0) {
-                const int B = 4 << p.gs_log2;
-                for (int eb = 0; eb < count; eb += B) {
+            // well-filled blocks of 16-lane rows: deal the entries by class (one wave pass per block, lane =
+            // sorted entry; the loads of all lanes have returned before the first store issues)
+            if (p.gs_log2 == 4) {
+                for (int eb = 0; eb < count; eb += WAVE) {
                     if (!block_interleaved(count, eb, p.gs_log2)) continue;
                     __threadfence_block();
+                    const bool real = eb + lane < count;
                     uint32_t wv = 0; uint16_t iv = 0;
-                    if (lane < B) { wv = p.w[d * p.stride + eb + lane]; iv = p.idx[d * p.stride + eb + lane]; }
+                    if (real) { wv = p.w[d * p.stride + eb + lane]; iv = p.idx[d * p.stride + eb + lane]; }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane < B) {
-                        p.w[d * p.stride + eb + interleaved_slot(lane, p.gs_log2)] = wv;
-                        p.idx[d * p.stride + eb + interleaved_slot(lane, p.gs_log2)] = iv;
+                    const int cls = iv & 15;
+                    int r = 0;                                   // rank among the entries of the same class
+                    for (int c = 0; c < 16; ++c) {
+                        const unsigned long long m = __ballot(real && cls == c);
+                        if (real && cls == c) r = below(m);
                     }
+                    int comp = r & 3, q = 0, used[4], freeb[5];
+                    for (int k = 0; k < 4; ++k) {                // lane inside the component, 16 places each
+                        const unsigned long long m = __ballot(real && comp == k);
+                        if (real && comp == k) q = below(m);
+                        used[k] = min(16, (int)__popcll(m));
+                    }
+                    const bool placed = real && q < 16;
+                    unsigned usedmask[4];                        // classes present in each component
+                    for (int k = 0; k < 4; ++k) {
+                        usedmask[k] = 0;
+                        for (int c = 0; c < 16; ++c)
+                            if (__ballot(placed && comp == k && cls == c)) usedmask[k] |= 1u << c;
+                    }
+                    freeb[0] = 0;
+                    for (int k = 0; k < 4; ++k) freeb[k + 1] = freeb[k] + 16 - used[k];
+                    if (!placed) {                               // leftovers take the free places in order
+                        const int j = below(__ballot(!placed));
+                        int k = 0;
+                        while (k < 3 && j >= freeb[k + 1]) ++k;
+                        const int jj = j - freeb[k];
+                        comp = k; q = used[k] + jj;
+                        if (!real) {                             // padding: jj-th class the component lacks
+                            int seen = 0, c = 0;
+                            for (; c < 15; ++c) {
+                                if (!((usedmask[k] >> c) & 1u)) { if (seen == jj) break; ++seen; }
+                            }
+                            iv = (uint16_t)c;                    // tile c has class c (n > 16 for 16-lane rows)
+                        }
+                    }
+                    p.w[d * p.stride + eb + q * 4 + comp] = wv;
+                    p.idx[d * p.stride + eb + q * 4 + comp] = iv;
                 }
             }
         }
@@ -495,7 +536,8 @@ __global__ void k_wtab(const WtabParams p) {
     if (FILL && wave == 0) {            // row D: the all-zero row idle lanes of the gather point at
         for (int pos = lane; pos < p.stride; pos += WAVE) {
             p.w[p.D * p.stride + pos] = 0u;
-            p.idx[p.D * p.stride + pos] = (uint16_t)(pos % p.n);
+            // lane l of a 16-lane group adds its zeros to tile l: 16 classes, no conflict
+            p.idx[p.D * p.stride + pos] = (uint16_t)(p.gs_log2 == 4 ? (pos >> 2) & 15 : pos % p.n);
         }
         if (lane == 0) p.len[p.D] = 0;
     }
