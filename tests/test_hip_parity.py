@@ -317,6 +317,26 @@ def test_sweep_and_table_formulations_agree(native, engine):
         np.testing.assert_allclose(out[1]["weights"], out[0]["weights"], rtol=0, atol=2.0 ** -33 * 200 + 1e-12)
 
 
+@pytest.mark.parametrize("tile_count,fov,power", [(500, 120.0, 2.0), (1000, 120.0, 2.0), (250, 360.0, 1.0),
+                                                   (500, 40.0, 3.0), (200, 170.0, 0.5), (1000, 75.0, 2.0)])
+def test_class_dealt_rows_hold_every_entry(native, engine, tile_count, fov, power):
+    """Lattices whose weight-table rows use the bank-class layout (k_wtab: rows of 48 entries and more,
+    including classes that overflow a block, padding and row tails): the histogram of lattice 0 must
+    equal the sweep's entry for entry, on samples spread over the whole sphere."""
+    from viewport_entropy_toolkit import _synthetic
+    mu, mv = _synthetic.uniform_sphere_video(96, 160, base_seed=tile_count)
+    out = []
+    for policy in (-1, 1):
+        plan = make_plan(native, engine, [tile_count], policy=policy, fov=fov, power=power)
+        out.append(plan.spatial(mu=mu, mv=mv, want_weights=True))
+        if policy > 0:
+            assert plan.table_stride(0) >= 64
+        plan.close()
+    assert np.array_equal(out[0]["assign"], out[1]["assign"])
+    np.testing.assert_allclose(out[1]["weights"], out[0]["weights"], rtol=0, atol=2.0 ** -33 * 96 + 1e-12)
+    np.testing.assert_allclose(out[1]["entropy"], out[0]["entropy"], rtol=1e-8)
+
+
 def test_config5_transition_full_size_properties(native, engine):
     """BASELINE config 5: 512 users x 10000 frames, tile_counts=[200], transition mode."""
     U, T = 512, 10000
