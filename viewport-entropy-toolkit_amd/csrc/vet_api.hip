@@ -154,6 +154,20 @@ int ensure_ws(vet_ctx* c, size_t bytes) {
     return VET_OK;
 }
 
+// Tuning knobs come from the environment; a value outside [lo, hi] is ignored.
+int env_int(const char* name, int lo, int hi, int fallback) {
+    const char* e = getenv(name);
+    if (!e || !*e) return fallback;
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (end == e || *end != '\0' || v < lo || v > hi) return fallback;
+    return (int)v;
+}
+int env_threads(const char* name, int fallback) {       // workgroup size: whole waves, at most 1024 threads
+    const int v = env_int(name, 64, 1024, fallback);
+    return v % 64 == 0 ? v : fallback;
+}
+
 int grid_for(long work, int block, int n_cu) {
     long b = (work + block - 1) / block;
     long cap = (long)n_cu * 8;
@@ -173,9 +187,9 @@ int spatial_geometry(const vet_ctx* c, int n, int U, bool weighted, Geometry* g)
         // k_spatial_u: one wave per frame in the entropy phase; keep >= 2048 samples per workgroup
         g->R = 1; g->G = 1; g->UC = 0;
         g->NW = 4;
-        if (const char* e = getenv("VET_U_WAVES")) g->NW = atoi(e);
+        g->NW = env_int("VET_U_WAVES", 1, 16, g->NW);
         g->FPW = U >= 2048 ? 2 : (U >= 512 ? 4 : (U >= 128 ? 8 : 32));
-        if (const char* e = getenv("VET_U_FPW")) g->FPW = atoi(e);
+        g->FPW = env_int("VET_U_FPW", 1, 64, g->FPW);
         while ((size_t)g->FPW * n * 4 > c->lds_max && g->FPW > 1) g->FPW /= 2;
         g->lds = (size_t)g->FPW * n * 4;
         if (g->lds > c->lds_max)
@@ -245,7 +259,7 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     (void)hipFree(d_max);
     if (e != hipSuccess) return fail(VET_ERR_DEVICE, "k_wtab<count> failed: %s", hipGetErrorString(e));
     int align = 64;      // rows start on 128-byte lines (u16 tile rows) / 256 bytes (u32 weight rows)
-    if (const char* e = getenv("VET_STRIDE_ALIGN")) align = atoi(e);
+    align = (env_int("VET_STRIDE_ALIGN", 64, 1024, align) + 63) / 64 * 64;   // whole 64-entry blocks: the walk reads whole blocks
     int stride = ((longest > 0 ? longest : 1) + align - 1) / align * align;
     const size_t bytes = (size_t)pl->n_dirs * stride * 6;
     if (bytes > kMaxTableBytes) { L.stride = -1; return VET_OK; }
@@ -259,10 +273,10 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     // lattices do not idle most of a group
     L.gs_log2 = 1;
     while (L.gs_log2 < 4 && (4 << L.gs_log2) < longest) ++L.gs_log2;
-    if (const char* e = getenv("VET_GS_LOG2")) L.gs_log2 = atoi(e);
+    L.gs_log2 = env_int("VET_GS_LOG2", 1, 4, L.gs_log2);
     // 16-lane rows with at least one block that is 3/4 full get the class-dealt layout (k_wtab)
     L.interleaved = L.gs_log2 == 4 && stride % 64 == 0 && 4 * longest >= 3 * 64;
-    if (const char* e = getenv("VET_TAB_INTERLEAVE")) L.interleaved = L.interleaved && atoi(e) != 0;
+    L.interleaved = L.interleaved && env_int("VET_TAB_INTERLEAVE", 0, 1, 1) != 0;
     p.stride = stride; p.w = L.d_tab_w; p.idx = L.d_tab_i; p.len = L.d_tab_len; p.maxcount = nullptr;
     p.gs_log2 = L.interleaved ? L.gs_log2 : -1;
     {
@@ -339,7 +353,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
             q.status = d_status;
             q.UC = U < 2048 ? U : 2048;
             int fpw = lut_frames_per_wg(U, T, c->n_cu);
-            if (const char* e = getenv("VET_LUT_FPW")) fpw = atoi(e) > 0 ? atoi(e) : fpw;
+            fpw = env_int("VET_LUT_FPW", 1, 16, fpw);
             size_t lds = 0;
             for (;; fpw /= 2) {
                 lds = (size_t)fpw * q.n_sum * 8 + (size_t)fpw * q.UC * 6 + (size_t)2 * fpw * 4 + 64;
@@ -349,7 +363,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
                 q.FPW = fpw;
                 const int blocks = (T + fpw - 1) / fpw;
                 int threads = 256;
-                if (const char* e = getenv("VET_LUT_THREADS")) threads = atoi(e);
+                threads = env_threads("VET_LUT_THREADS", threads);
                 bool il = false;
                 for (int k = 0; k < K; ++k) il = il || pl->lat[k].interleaved;
                 ProfScope ps(c, s, KID_SPATIAL);
@@ -409,7 +423,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
                 q.FPW = FB;
                 const long nblk = ((long)T + FB - 1) / FB;
                 long grid = (long)c->n_cu * 2;
-                if (const char* e = getenv("VET_U_WGS_PER_CU")) grid = (long)c->n_cu * atoi(e);
+                grid = (long)c->n_cu * env_int("VET_U_WGS_PER_CU", 1, 8, 2);
                 if (grid > nblk) grid = nblk;
                 // even rounds: every persistent workgroup walks the same number of blocks (no tail)
                 const long rounds = (nblk + grid - 1) / grid;
@@ -475,7 +489,7 @@ int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, dou
         p.HS = HS; p.hs_shift = 32 - lg;
         p.log2_tab = c->d_log2;
         int threads = U > 1024 ? 512 : 256;      // measured: 256 is best at U = 512 (profiles/r01)
-        if (const char* e = getenv("VET_T_THREADS")) threads = atoi(e);
+        threads = env_threads("VET_T_THREADS", threads);
         ProfScope ps(c, s, KID_TRANSITION);
         hipLaunchKernelGGL((vet::k_transition<FROM_IDS>), dim3(8 * ((R + 7) / 8)), dim3(threads), lds, s, p);
         HIP_TRY(hipGetLastError());
