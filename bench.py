@@ -39,6 +39,9 @@ WORKLOADS = {
     "config5": (512, 10000, [200], "transition", True),
     # 64 config-2-sized videos per GPU in one launch (vet_spatial_entropy_batch); --loop runs them one by one
     "config2x64": (64, 3000, [50, 100, 200], "spatial", True),
+    # the reference's default AnalyzerConfig.tile_counts (config.py:27) on a config-4-sized video
+    "defaults": (256, 10000, [20, 50, 100, 250, 1000], "spatial", True),
+    "defaults_u": (256, 10000, [20, 50, 100, 250, 1000], "spatial", False),
 }
 BATCH = {"config2x64": 64}
 

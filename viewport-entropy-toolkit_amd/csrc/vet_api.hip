@@ -291,14 +291,17 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
 // Frames per workgroup of the table kernel: about 1024 samples per workgroup, at most one frame per
 // wave (the epilogue reduces a frame per wave, and every frame costs n_sum * 8 B of LDS), and never
 // so many that the launch has fewer than ~4 workgroups per CU (measured: config 4 best at 4 frames
-// x 256 users, config 2 at 2 x 64 with only 3000 frames; profiles/r01/v6_table_geometry_sweep.log).
-int lut_frames_per_wg(int U, long total_frames, int n_cu) {
+// x 256 users, config 2 at 2 x 64 with only 3000 frames; the reference's five default lattices, 1425
+// tiles, at 1 x 256: profiles/r01/v6_table_geometry_sweep.log).
+int lut_frames_per_wg(int U, long total_frames, int n_cu, int n_sum) {
     long f = 1024 / (U > 0 ? U : 1);
     const long by_grid = total_frames / (4L * n_cu);
     if (f > by_grid) f = by_grid;
     if (f > 4) f = 4;
     int fpw = 1;
     while (2 * fpw <= f) fpw *= 2;
+    // keep ~7 workgroups per CU resident: at most ~20 KB of LDS histograms per workgroup
+    while (fpw > 1 && (size_t)fpw * n_sum * 8 > 20 * 1024) fpw /= 2;
     return fpw;
 }
 
@@ -352,7 +355,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
             q.entropy = d_entropy; q.assign = d_assign; q.weights = d_weights; q.present = d_present;
             q.status = d_status;
             q.UC = U < 2048 ? U : 2048;
-            int fpw = lut_frames_per_wg(U, T, c->n_cu);
+            int fpw = lut_frames_per_wg(U, T, c->n_cu, q.n_sum);
             fpw = env_int("VET_LUT_FPW", 1, 16, fpw);
             size_t lds = 0;
             for (;; fpw /= 2) {
@@ -875,7 +878,7 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
             d.mu = x.d_mu; d.mv = x.d_mv; d.U = x.n_users; d.T = x.n_frames;
             d.entropy = x.d_entropy; d.assign = x.d_assign; d.present = x.d_present;
             d.UC = d.U < 2048 ? d.U : 2048;
-            int fpw = lut_frames_per_wg(d.U, total_frames, c->n_cu);
+            int fpw = lut_frames_per_wg(d.U, total_frames, c->n_cu, n_sum);
             size_t lds = 0;
             for (;; fpw /= 2) {
                 lds = (size_t)fpw * n_sum * 8 + (size_t)fpw * d.UC * 6 + (size_t)2 * fpw * 4 + 64;
