@@ -22,9 +22,9 @@ def engine(native):
 
 
 problem = st.fixed_dictionaries(dict(
-    U=st.integers(1, 70), T=st.integers(1, 12), seed=st.integers(0, 2 ** 31 - 1),
+    U=st.one_of(st.integers(1, 70), st.integers(71, 300)), T=st.integers(1, 12), seed=st.integers(0, 2 ** 31 - 1),
     p_absent=st.sampled_from([0.0, 0.1, 0.5]),
-    tcs=st.lists(st.sampled_from([1, 2, 3, 20, 50, 64, 65, 100, 129, 250]), min_size=1, max_size=3),
+    tcs=st.lists(st.sampled_from([1, 2, 3, 20, 50, 64, 65, 100, 129, 250, 500, 1000]), min_size=1, max_size=3),
     fov=st.sampled_from([30.0, 90.0, 120.0, 150.0, 360.0]), power=st.sampled_from([0.5, 1.0, 2.0, 3.0]),
     mode=st.sampled_from(["sweep", "table", "unweighted", "transition"]),
     edge=st.booleans()))
@@ -45,7 +45,7 @@ def make_samples(pr):
     return mu, mv
 
 
-@settings(max_examples=80, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=120, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(problem)
 def test_hip_matches_oracle(native, engine, pr):
     mu, mv = make_samples(pr)
