@@ -321,6 +321,33 @@ def main():
                 out["roofline"]["secondary"] = {
                     "bound": "fp64 valu (13.5 flop per tile and sample, SURVEY.md 8d)", "flop_per_launch": flop,
                     "achieved": flop / (avg_kernel_ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s"}
+        if world == 1 and mode == "spatial" and weighted and n_batch == 1:
+            # the same video with use_weight_distribution=False (every user counts 1 on its nearest
+            # tile): the HBM-streaming formulation of the path, reported beside the headline
+            plan_u = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in tcs], 120.0, 2.0, False, 100, 200)
+            for _ in range(args.warmup):
+                plan_u.spatial_device(mu.data_ptr(), mv.data_ptr(), U, T, ent.data_ptr(), d_assign=idx.data_ptr(),
+                                      d_status=status.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            eng.profile_enable(True)
+            eng.profile_reset()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                plan_u.spatial_device(mu.data_ptr(), mv.data_ptr(), U, T, ent.data_ptr(), d_assign=idx.data_ptr(),
+                                      d_status=status.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.steps
+            ku_ms, ku_n = eng.profile_get("k_spatial")
+            eng.profile_enable(False)
+            plan_u.close()
+            per_launch = alg_bytes_step / max(ku_n / args.steps, 1.0)
+            out["nearest_tile_variant"] = {
+                "config": "same video, use_weight_distribution=False", "ms_per_step": dt * 1e3,
+                "value": U * T / dt, "unit": "samples/s",
+                "roofline": {"bound": "hbm", "kernel": "k_spatial (k_spatial_u_lds)",
+                             "achieved": per_launch / (ku_ms / max(ku_n, 1) * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                             "unit": "GB/s", "frac": per_launch / (ku_ms / max(ku_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "avg_kernel_ms": ku_ms / max(ku_n, 1), "launches": ku_n}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mu_h, mv_h, tcs, mode, weighted, args.cpu_seconds)
         print(json.dumps(out), flush=True)
