@@ -61,6 +61,18 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Streamed once: non-temporal loads / stores keep the sample stream from displacing the tables in L2
+__device__ __forceinline__ double2 nt_load(const double2* p) {
+    double2 v;
+    v.x = __builtin_nontemporal_load(&p->x);
+    v.y = __builtin_nontemporal_load(&p->y);
+    return v;
+}
+__device__ __forceinline__ void nt_store(int2* p, int2 v) {
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+}
+
 // numpy-scalar round(v, 6) == rint(v * 1e6) / 1e6   (data_types.py:213-215)
 __device__ __forceinline__ double round6(double v) { return rint(v * 1e6) / 1e6; }
 
@@ -136,13 +148,14 @@ __device__ __forceinline__ int grid_dir(double m, double v, int W, int H, bool& 
 }
 
 // returns direction id, -1 when absent; sets bad when a value is outside [0,1]
-template <bool FROM_IDS>
+template <bool FROM_IDS, bool NT = true>
 __device__ __forceinline__ int sample_dir(const SampleSrc& s, long idx, bool& bad) {
     if (FROM_IDS) {
         const int id = s.ids[idx];
         if (id >= s.n_dirs) { bad = true; return -1; }
         return id < 0 ? -1 : id;
     } else {
+        if (NT) return grid_dir(__builtin_nontemporal_load(s.mu + idx), __builtin_nontemporal_load(s.mv + idx), s.W, s.H, bad);
         return grid_dir(s.mu[idx], s.mv[idx], s.W, s.H, bad);
     }
 }
@@ -324,7 +337,7 @@ __global__ void k_spatial_w(const SpatialParams p) {
                 dst[1] = p.dir_unit[3 * (long)id + 1];
                 dst[2] = p.dir_unit[3 * (long)id + 2];
             }
-            if (p.assign) p.assign[idx] = id >= 0 ? (int)p.nearest[id] : -1;
+            if (p.assign) __builtin_nontemporal_store(id >= 0 ? (int)p.nearest[id] : -1, p.assign + idx);
         }
         __syncthreads();
         for (int i = tid; i < p.FPW; i += blockDim.x) cnt_frame[i] += cnt_chunk[i];
@@ -712,7 +725,7 @@ __global__ void k_spatial_lut(const LutParams p) {
             const long idx = (f0 + fl) * (long)U + u0 + uu;
             const int id = sample_dir<FROM_IDS>(src, idx, bad);
             if (id >= 0) ids[(size_t)fl * UC + atomicAdd(&cnt_chunk[fl], 1)] = id;
-            if (assign) assign[idx] = id >= 0 ? (int)p.nearest[id] : -1;
+            if (assign) __builtin_nontemporal_store(id >= 0 ? (int)p.nearest[id] : -1, assign + idx);
         }
         __syncthreads();
         for (int i = tid; i < FPW; i += blockDim.x) cnt_frame[i] += cnt_chunk[i];
@@ -855,7 +868,7 @@ __global__ void k_spatial_u(const SpatialParams p) {
                 near = p.nearest[id];
                 atomicAdd(&cnt[(size_t)fl * p.n + near], 1u);
             }
-            if (p.assign) p.assign[idx] = near;
+            if (p.assign) __builtin_nontemporal_store(near, p.assign + idx);
         }
     }
     __syncthreads();
@@ -942,7 +955,7 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int i = tid + k * (int)blockDim.x;
-            if (i < nitems) { a[k] = mu2[i]; b[k] = mv2[i]; }
+            if (i < nitems) { a[k] = nt_load(mu2 + i); b[k] = nt_load(mv2 + i); }
         }
     }
     for (long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
@@ -973,7 +986,7 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
                     const int i = tid + k * (int)blockDim.x;
-                    if (i < nnext) { a[k] = mu2[i]; b[k] = mv2[i]; }
+                    if (i < nnext) { a[k] = nt_load(mu2 + i); b[k] = nt_load(mv2 + i); }
                 }
             }
 #pragma unroll
@@ -984,7 +997,7 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
                     unsigned* row = cnt + (size_t)fl * p.n;
                     if (near[k][0] >= 0) atomicAdd(&row[near[k][0]], 1u);
                     if (near[k][1] >= 0) atomicAdd(&row[near[k][1]], 1u);
-                    if (out2) out2[i] = make_int2(near[k][0], near[k][1]);
+                    if (out2) nt_store(out2 + i, make_int2(near[k][0], near[k][1]));
                 }
             }
         } else {
@@ -995,7 +1008,7 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
 #pragma unroll
             for (int k = 0; k < 2 * PPT; ++k) {
                 const int i = tid + k * (int)blockDim.x;
-                if (i < nitems) { a[k] = mu1[i]; b[k] = mv1[i]; }
+                if (i < nitems) { a[k] = __builtin_nontemporal_load(mu1 + i); b[k] = __builtin_nontemporal_load(mv1 + i); }
             }
 #pragma unroll
             for (int k = 0; k < 2 * PPT; ++k) {
@@ -1005,7 +1018,7 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
                     const int id0 = grid_dir(a[k], b[k], p.src.W, p.src.H, bad);
                     const int n0 = id0 >= 0 ? (int)lut[id0] : -1;
                     if (n0 >= 0) atomicAdd(&cnt[(size_t)fl * p.n + n0], 1u);
-                    if (out1) out1[i] = n0;
+                    if (out1) __builtin_nontemporal_store(n0, out1 + i);
                 }
             }
         }
@@ -1107,8 +1120,9 @@ __global__ void k_transition(const TransParams p) {
     bool bad = false;
     int mine = 0;
     for (int u = tid; u < p.U; u += blockDim.x) {
-        const int ia = sample_dir<FROM_IDS>(p.src, r * (long)p.U + u, bad);
-        const int ib = sample_dir<FROM_IDS>(p.src, (r + 1) * (long)p.U + u, bad);
+        // cached loads here: frame r+1 is read again by row r+1 of the same XCD
+        const int ia = sample_dir<FROM_IDS, false>(p.src, r * (long)p.U + u, bad);
+        const int ib = sample_dir<FROM_IDS, false>(p.src, (r + 1) * (long)p.U + u, bad);
         unsigned packed = EMPTY_KEY;
         int pa = -1, cb = -1;
         if (ia >= 0 && ib >= 0) {           // user present in both frames (entropy_utils.py:259-261)
