@@ -1133,9 +1133,9 @@ __global__ void k_transition(const TransParams p) {
             ++mine;
         }
         pc[u] = packed;
-        if (p.pairs) {
-            p.pairs[(r * (long)p.U + u) * 2] = pa;
-            p.pairs[(r * (long)p.U + u) * 2 + 1] = cb;
+        if (p.pairs) {      // written once: non-temporal
+            __builtin_nontemporal_store(pa, p.pairs + (r * (long)p.U + u) * 2);
+            __builtin_nontemporal_store(cb, p.pairs + (r * (long)p.U + u) * 2 + 1);
         }
     }
     mine = wave_sum(mine);
