@@ -242,7 +242,7 @@ __device__ __forceinline__ void weighted_frame_entropy(const unsigned long long*
                 const double q = (double)v / totd;
                 h -= q * log2(q);
             }
-            if (weights) weights[(f0 + fl) * (long)n + t] = (double)v / fx_scale;
+            if (weights) __builtin_nontemporal_store((double)v / fx_scale, weights + (f0 + fl) * (long)n + t);
         }
         h = wave_sum(h);
         if (lane == 0) {
@@ -770,7 +770,7 @@ __global__ void k_spatial_lut(const LutParams p) {
                     const double q = (double)v / totd;
                     h -= q * log2(q);
                 }
-                if (k == 0 && weights) weights[(f0 + fl) * (long)n + t] = (double)v / 4294967296.0;
+                if (k == 0 && weights) __builtin_nontemporal_store((double)v / 4294967296.0, weights + (f0 + fl) * (long)n + t);
             }
             h = wave_sum(h);
             total_entropy += h / p.lat[k].hmax;
@@ -885,7 +885,7 @@ __global__ void k_spatial_u(const SpatialParams p) {
                 const double q = (double)v / tw;
                 h -= q * log2(q);
             }
-            if (p.weights) p.weights[(f0 + fl) * (long)p.n + t] = (double)v;
+            if (p.weights) __builtin_nontemporal_store((double)v, p.weights + (f0 + fl) * (long)p.n + t);
         }
         h = wave_sum(h);
         if (lane == 0) {
@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
             for (int t = lane; t < p.n; t += WAVE) {
                 const unsigned v = row[t];
                 if (v) h -= ((double)v * inv_tw) * (lg[v] - lgn);
-                if (WEIGHTS) wout[t] = (double)v;
+                if (WEIGHTS) __builtin_nontemporal_store((double)v, wout + t);
                 row[t] = 0u;
             }
             h = wave_sum(h);
