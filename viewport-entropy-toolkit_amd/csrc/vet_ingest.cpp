@@ -8,7 +8,7 @@
 // last-bit difference can move a sample to another pixel.  Anything outside plain unquoted numeric
 // CSV (quotes, text, inf, odd row shapes, > 17-digit integers, ...) is reported as
 // VET_CSV_FALLBACK and the caller parses that file with pandas itself; the Python side also
-// cross-checks the first file of every directory against pandas.
+// cross-checks the first file a process reads against pandas.
 //
 // Host code only: no HIP calls, usable without a GPU.
 

@@ -84,23 +84,27 @@ def read_samples(filepath: Union[str, Path], width: int, height: int, columns=No
         raise ValidationError(f"Error processing viewport data: {str(e)}")
 
 
+_native_state = {"verified": None}      # None = not checked yet, True / False = result of the check against pandas
+
+
 def read_directory(files: Sequence[Path], width: int, height: int, threads: int = 0):
     """All user files of one video -> list of ``read_samples`` results, in ``files`` order.
 
     ``VET_CSV_PARSER`` = ``native`` (default when libvet_hip.so is built): the C-ABI's threaded
     loader (vet_csv_read_tracks) parses the plain numeric files, pandas the ones it declines, and
-    the first file is parsed both ways and compared, so a pandas whose converter differs sends the
-    whole directory through pandas; ``pandas``: ``pd.read_csv`` for every file, as the reference."""
+    the first file a process reads is parsed both ways and compared, so a pandas whose converter
+    differs sends everything through pandas; ``pandas``: ``pd.read_csv`` for every file, as the reference."""
     files = [Path(f) for f in files]
     mode = os.environ.get("VET_CSV_PARSER", "native")
     parsed = None
-    if mode != "pandas" and files:
+    if mode != "pandas" and files and _native_state["verified"] is not False:
         try:
             from . import _native
             parsed = _native.read_tracks(files, threads)
         except Exception:  # noqa: BLE001 - library not built: the reference's own parser does the job
             parsed = None
-        if parsed is not None:
+        if parsed is not None and _native_state["verified"] is None:
+            # once per process: the converter must agree with this pandas bit for bit on a real file
             first = next((i for i, p in enumerate(parsed) if p[0] == 0), None)
             if first is not None:
                 try:
@@ -108,10 +112,12 @@ def read_directory(files: Sequence[Path], width: int, height: int, threads: int 
                     same = all(np.array_equal(x, y, equal_nan=True) for x, y in zip((t, a, b), parsed[first][1:]))
                 except Exception:  # noqa: BLE001
                     same = False
+                _native_state["verified"] = same
                 if not same:
                     logging.getLogger(__name__).warning("native CSV loader disagrees with pandas on %s; using pandas",
                                                         files[first])
-                    parsed = None
+        if _native_state["verified"] is False:
+            parsed = None
     out = []
     for i, fp in enumerate(files):
         cols = parsed[i][1:] if parsed is not None and parsed[i][0] == 0 else None
