@@ -82,7 +82,7 @@ struct Lattice {
     uint16_t* d_tab_len = nullptr; // [n_dirs]
     int stride = 0;                // 0 = not built, -1 = not usable (too large)
     int gs_log2 = 4;               // lanes per gather group (log2); fixed when the table is built
-    bool interleaved = false;      // row entries dealt round-robin over the group's lanes (slot_of)
+    bool interleaved = false;      // well-filled row blocks are dealt by LDS bank class (k_wtab)
     bool binned = false;           // caller-supplied direction -> bin table (naive lat/lon tiling)
     int norm_n = 0;                // tile count used by the normaliser rule
 };
@@ -100,7 +100,7 @@ struct vet_plan {
     double cos_cull = 0.0;
     int table_policy = 0;          // 0 auto, 1 always use the weight table, -1 never
     long samples_seen = 0;         // samples this plan has processed (auto policy: tables pay off
-                                   // once a plan has seen as many samples as it has directions)
+                                   // once a plan has seen 16 samples per direction, want_table)
 };
 
 namespace {
@@ -144,7 +144,8 @@ int collect_profile(vet_ctx* c) {
 
 int ensure_ws(vet_ctx* c, size_t bytes) {
     if (bytes <= c->ws_bytes) return VET_OK;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // earlier calls may still use the old workspace on a caller's stream: wait for the device
+    HIP_TRY(hipDeviceSynchronize());
     if (c->ws) HIP_TRY(hipFree(c->ws));
     c->ws = nullptr;
     c->ws_bytes = 0;
