@@ -264,6 +264,10 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     int stride = ((longest > 0 ? longest : 1) + align - 1) / align * align;
     const size_t bytes = (size_t)pl->n_dirs * stride * 6;
     if (bytes > kMaxTableBytes) { L.stride = -1; return VET_OK; }
+    // a failed earlier attempt may have left buffers behind
+    if (L.d_tab_w) { (void)hipFree(L.d_tab_w); L.d_tab_w = nullptr; }
+    if (L.d_tab_i) { (void)hipFree(L.d_tab_i); L.d_tab_i = nullptr; }
+    if (L.d_tab_len) { (void)hipFree(L.d_tab_len); L.d_tab_len = nullptr; }
     // one extra, all-zero row (index n_dirs) for the gather's idle lanes
     HIP_TRY(hipMalloc((void**)&L.d_tab_w, (size_t)(pl->n_dirs + 1) * stride * 4));
     HIP_TRY(hipMalloc((void**)&L.d_tab_i, (size_t)(pl->n_dirs + 1) * stride * 2));
