@@ -100,6 +100,8 @@ def read_directory(files: Sequence[Path], width: int, height: int, threads: int 
     if mode != "pandas" and files and _native_state["verified"] is not False:
         try:
             from . import _native
+            if threads <= 0:      # the CPUs this process may run on, not the machine's
+                threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 32)
             parsed = _native.read_tracks(files, threads)
         except Exception:  # noqa: BLE001 - library not built: the reference's own parser does the job
             parsed = None
