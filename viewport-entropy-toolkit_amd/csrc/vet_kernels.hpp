@@ -545,7 +545,9 @@ __global__ void k_wtab(const WtabParams p) {
         }
         longest = max(longest, count);
     }
-    if (!FILL && lane == 0 && longest > 0) atomicMax(p.maxcount, longest);
+    // a plain read first: the maximum only grows, so most waves find theirs already covered and skip
+    // the same-address atomic (2048 of them cost ~100 us)
+    if (!FILL && lane == 0 && longest > *(volatile int*)p.maxcount) atomicMax(p.maxcount, longest);
     if (FILL && wave == 0) {            // row D: the all-zero row idle lanes of the gather point at
         for (int pos = lane; pos < p.stride; pos += WAVE) {
             p.w[p.D * p.stride + pos] = 0u;
