@@ -376,8 +376,11 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
                 for (int k = 0; k < K; ++k) il = il || pl->lat[k].interleaved;
                 ProfScope ps(c, s, KID_SPATIAL);
                 // 2 rows in flight per lane group measured best (4 and 8 were tried, profiles/r01/v3_*)
-                if (il) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2, true>), dim3(blocks), dim3(threads), lds, s, q);
-                else hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2, false>), dim3(blocks), dim3(threads), lds, s, q);
+                const bool occ8 = K == 1 && threads == 256;
+                if (il && occ8) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2, true, true>), dim3(blocks), dim3(threads), lds, s, q);
+                else if (il) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2, true, false>), dim3(blocks), dim3(threads), lds, s, q);
+                else if (occ8) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2, false, true>), dim3(blocks), dim3(threads), lds, s, q);
+                else hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2, false, false>), dim3(blocks), dim3(threads), lds, s, q);
                 HIP_TRY(hipGetLastError());
                 return VET_OK;
             }
@@ -734,10 +737,14 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
             PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<false>(wm, R), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
             PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<true>(wm, R), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
         }
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 2, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 2, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
@@ -917,8 +924,8 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
             ProfScope ps(c, s, KID_SPATIAL);
             bool il = false;
             for (int k = 0; k < K; ++k) il = il || pl->lat[k].interleaved;
-            if (il) hipLaunchKernelGGL((vet::k_spatial_lut<false, 2, true>), dim3((unsigned)block), dim3(256), lds_max, s, q);
-            else hipLaunchKernelGGL((vet::k_spatial_lut<false, 2, false>), dim3((unsigned)block), dim3(256), lds_max, s, q);
+            if (il) hipLaunchKernelGGL((vet::k_spatial_lut<false, 2, true, true>), dim3((unsigned)block), dim3(256), lds_max, s, q);
+            else hipLaunchKernelGGL((vet::k_spatial_lut<false, 2, false, true>), dim3((unsigned)block), dim3(256), lds_max, s, q);
             HIP_TRY(hipGetLastError());
             return VET_OK;
         }

@@ -682,8 +682,11 @@ struct LutParams {
 // gathered into K histograms, and avg_entropy = (e_0 + ... + e_{K-1}) / K is formed in lattice
 // order as the reference does (spatial_entropy.py:142-156) — no per-lattice pass, no finalize.
 // IL: some lattice of the plan has interleaved rows (otherwise only the plain walk is compiled in).
-template <bool FROM_IDS, int UN, bool IL>
-__global__ void k_spatial_lut(const LutParams p) {
+// OCC8: compiled for 8 workgroups of 256 threads per CU (64 VGPRs) instead of 7 (68-70 VGPRs): measured
+// 2 % (random walk) to 6.5 % (clustered) faster on single-lattice plans and 7 % on batches of short
+// videos, but 2-4 % slower on one multi-lattice video (profiles/r01/v6_table_occupancy.log).
+template <bool FROM_IDS, int UN, bool IL, bool OCC8>
+__global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // the video this workgroup works on: the launch's only one, or one of a batch
     SampleSrc src = p.src;
