@@ -66,6 +66,15 @@ def synth_video(U, T, seed, video_id, kind="random_walk"):
     return np.ascontiguousarray(mu), np.ascontiguousarray(mv)
 
 
+def kernel_src_sha():
+    """Hash of the device code: PMC records are only valid for the sources they were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("vet_kernels.hpp", "vet_api.hip"):
+        h.update((ROOT / "viewport-entropy-toolkit_amd" / "csrc" / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -133,14 +142,26 @@ def main():
                          "axis with a 1-frame halo in transition mode (strong scaling, BASELINE config 5)")
     args = ap.parse_args()
 
+    # --gpus N without an outer launcher: start the N ranks ourselves, as a CHILD process and before
+    # anything here touches torch or HIP (a process that has initialised the GPU must not exec).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would report the wrong n_gpus")
     multi = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ     # under torch.distributed.run: RCCL path
     # VET_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than
     # ranks (ranks share devices, the gather goes through host memory); the real runs use RCCL.
@@ -190,7 +211,11 @@ def main():
     plan = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in tcs], 120.0, 2.0, weighted, 100, 200)
     eng.synchronize()
     plan_ms = (time.perf_counter() - t0) * 1e3
-    stream = torch.cuda.current_stream().cuda_stream
+    # everything of a step — the engine's kernels, the copy into the gather buffer, the RCCL gather — is
+    # enqueued on ONE explicit stream, so the gather is ordered after the kernel that produces its input
+    run_stream = torch.cuda.Stream(device=dev)
+    stream = run_stream.cuda_stream
+    torch.cuda.synchronize()
 
     n_batch = BATCH.get(args.workload, 1)
     if n_batch > 1:
@@ -230,26 +255,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    eng.profile_enable(True)
-    eng.profile_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    with torch.cuda.stream(run_stream):
+        for _ in range(args.warmup):
+            step()
+        fence()
+        eng.profile_enable(True)
+        eng.profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
     kname = "k_spatial" if mode == "spatial" else "k_transition"
     if mode == "transition":
         formulation = "k_transition: nearest-tile LUT gather + LDS bucket statistics"
     elif not weighted:
         formulation = "k_spatial_u(_lds): nearest-tile LUT + integer histogram stream"
-    elif plan.table_stride(0) > 0:
-        formulation = (f"k_spatial_lut: direction weight table gather (rows of {plan.table_stride(0)} entries, "
-                       f"{len(tcs)} lattice(s) fused in one launch)")
+    elif plan.last_formulation(0) == "table":
+        formulation = (f"k_spatial_lut: direction weight table gather over the distinct directions of a frame (rows of "
+                       f"{plan.table_stride(0)} entries, {len(tcs)} lattice(s) fused in one launch)")
     else:
-        formulation = "k_spatial_w: brute-force FP64 sweep"
+        formulation = f"k_spatial_w: brute-force FP64 sweep ({plan.last_formulation(0)})"
     k_ms, k_n = eng.profile_get(kname)
     fin_ms, fin_n = eng.profile_get("k_finalize")
     eng.profile_enable(False)
@@ -274,11 +300,17 @@ def main():
         alg_bytes_launch = alg_bytes_step / launches_per_step
         avg_kernel_ms = k_ms / max(k_n, 1)
         achieved = alg_bytes_launch / (avg_kernel_ms * 1e-3) / 1e9 if k_n else None
-        traffic = None
+        # PMC traffic is collected in separate rocprofv3 --pmc passes (tools/pmc.sh) and recorded with the
+        # hash of the kernel sources it was measured on; a stale record is dropped, not replayed
+        traffic, traffic_src = None, None
         tf = ROOT / "profiles" / "pmc_traffic.json"
-        if tf.exists():
+        if tf.exists() and args.data == "random_walk":
             try:
-                traffic = json.loads(tf.read_text()).get(args.workload, {}).get("hbm_bytes_per_launch")
+                rec = json.loads(tf.read_text()).get(args.workload, {})
+                if rec.get("kernel_src_sha") == kernel_src_sha():
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_src = {"file": "profiles/pmc_traffic.json", "kernel_ms_at_collection": rec.get("kernel_ms"),
+                                   "kernel_src_sha": rec.get("kernel_src_sha")}
             except Exception:  # noqa: BLE001
                 traffic = None
         out = {
@@ -295,11 +327,13 @@ def main():
             "frames_per_s": (T_total if strong else R * world) * n_batch / (ms_per_step * 1e-3),
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes_launch,
+                         "traffic": traffic, "traffic_provenance": traffic_src,
+                         "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "avg_kernel_ms": avg_kernel_ms, "launches": k_n,
-                         "note": ("weighted FoV histogram: the table gather moves ~6*stride B/sample from L2/"
-                                  "Infinity Cache on top of the algorithmic bytes; bound by gather bandwidth, "
-                                  "not HBM (DESIGN.md §5)") if (mode == "spatial" and weighted) else
+                         "note": ("weighted FoV histogram: on top of the algorithmic bytes the gather moves 6 B per in-FoV "
+                                  "tile of every distinct direction of a frame from L2 / Infinity Cache and issues one "
+                                  "LDS atomic per entry; see `secondary` for that formulation's own speed of light "
+                                  "(DESIGN.md §5)") if (mode == "spatial" and weighted) else
                                  "integer histogram stream: HBM-bound"},
             "kernel_ms_per_step": {kname: k_ms / args.steps, "k_finalize": fin_ms / args.steps},
             "formulation": formulation,
@@ -309,13 +343,28 @@ def main():
         if mode == "spatial" and weighted and k_n:
             n_lat = [2 * (tc // 2) + 1 for tc in tcs]
             cap = (1.0 - np.cos(np.radians(120.0 / 2.0))) / 2.0          # share of tiles inside the FoV cap
-            if plan.table_stride(0) > 0:
-                gathered = 6.0 * cap * sum(n_lat) * U * T * n_batch / launches_per_step
+            if plan.last_formulation(0) == "table":
+                # speed of light of THIS formulation: a frame gathers one 6-byte entry per in-FoV tile of each
+                # DISTINCT direction among its users and issues one 64-bit LDS atomic per entry
+                dirs = plan.read_dirs()
+                _, alias = np.unique(dirs + 0.0, axis=0, return_inverse=True)
+                ids = (mv_h * 200).astype(np.int64) * 101 + (mu_h * 100).astype(np.int64)
+                rows = np.sort(alias.reshape(-1)[ids], axis=1)
+                distinct = 1 + (np.diff(rows, axis=1) != 0).sum(1)
+                entries = float(distinct.sum()) * cap * sum(n_lat) * n_batch / launches_per_step
+                cu, clk = 256, 2.4e9
+                lds_rate = 64 / 6.6 * clk * cu                      # conflict-free ds_add_u64: 6.6 clk per wave (probed)
+                t_l2, t_mall = 6 * entries / (70e9 * cu), 6 * entries / (33.5e9 * cu)
+                t_lds = entries / lds_rate
                 out["roofline"]["secondary"] = {
-                    "bound": "cache-hierarchy row gather (6 B per in-FoV tile and sample, estimated from the cap area)",
-                    "gathered_bytes_per_launch": gathered,
-                    "achieved": gathered / (avg_kernel_ms * 1e-3) / 1e9 / 256.0, "unit": "GB/s per CU",
-                    "guide_rates": {"xcd_l2": [66, 73], "infinity_cache": 33.5, "hbm": [23, 24]}}
+                    "bound": "row gather (6 B per entry through L2 / Infinity Cache) and one ds_add_u64 per entry",
+                    "distinct_directions_per_frame": float(distinct.mean()), "users_per_frame": U,
+                    "entries_per_launch": entries, "gathered_bytes_per_launch": 6 * entries,
+                    "achieved": 6 * entries / (avg_kernel_ms * 1e-3) / 1e9 / cu, "unit": "GB/s per CU",
+                    "guide_rates_GBps_per_cu": {"xcd_l2": [66, 73], "infinity_cache": 33.5, "hbm": [23, 24]},
+                    "sol_ms": {"gather_all_l2_hits": t_l2 * 1e3, "gather_all_infinity_cache": t_mall * 1e3,
+                               "lds_atomics_conflict_free": t_lds * 1e3},
+                    "frac_of_sol": max(t_l2, t_lds) / (avg_kernel_ms * 1e-3)}
             else:
                 flop = 13.5 * sum(n_lat) * U * T * n_batch / launches_per_step
                 out["roofline"]["secondary"] = {
@@ -325,6 +374,7 @@ def main():
             # the same video with use_weight_distribution=False (every user counts 1 on its nearest
             # tile): the HBM-streaming formulation of the path, reported beside the headline
             plan_u = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in tcs], 120.0, 2.0, False, 100, 200)
+            torch.cuda.set_stream(run_stream)
             for _ in range(args.warmup):
                 plan_u.spatial_device(mu.data_ptr(), mv.data_ptr(), U, T, ent.data_ptr(), d_assign=idx.data_ptr(),
                                       d_status=status.data_ptr(), stream=stream)

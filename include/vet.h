@@ -19,8 +19,13 @@
  *     reference's ``vectors_df``: one row per frame, one column per user);
  *     an absent sample (reference: ``None`` cell) is NaN in mu or mv, or id -1;
  *   - "d_" parameters are device pointers, "h_" parameters are host pointers;
- *   - ``stream`` is a hipStream_t passed as void* (NULL = the context's stream).
- *     Device-pointer entry points only enqueue work; they do not synchronise.
+ *   - ``stream`` is a hipStream_t passed as void*.  NULL selects the CONTEXT'S OWN stream
+ *     (hipStreamNonBlocking: not ordered against the null stream) — it is NOT the null stream.
+ *     To run on the legacy default stream (what torch calls its default stream, handle 0) pass
+ *     VET_STREAM_LEGACY; any other value is used as the hipStream_t it is.
+ *     Device-pointer entry points only enqueue work; they do not synchronise.  A context is
+ *     single-threaded, and calls that share its scratch (vet_spatial_entropy_batch's descriptor
+ *     buffer, the K > 1 workspace) must be issued on one stream or be synchronised in between.
  *   - there is no CPU fallback: without a gfx950 device vet_create() fails.
  */
 #ifndef VET_H_
@@ -33,7 +38,8 @@
 extern "C" {
 #endif
 
-#define VET_VERSION 100 /* 0.1.0 */
+#define VET_VERSION 110 /* 0.1.1 */
+#define VET_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy: the null stream with legacy ordering */
 
 enum {
     VET_OK = 0,
@@ -114,14 +120,27 @@ typedef struct vet_plan_desc {
 int vet_plan_create(vet_ctx *ctx, const vet_plan_desc *desc, vet_plan **out);
 int vet_plan_destroy(vet_plan *plan);
 int64_t vet_plan_n_dirs(const vet_plan *plan);
-/* Weighted spatial mode has two formulations with identical results up to the fixed-point
- * resolution: (a) brute force, every sample sweeps every tile (FP64 VALU bound); (b) direction
- * weight table, built once per plan and gathered per sample (memory bound).  policy: 0 auto
- * (table once the plan has processed 16 samples per direction of its table), 1 always table,
- * -1 never.  vet_plan_table_stride: row length of lattice k's table, 0 = not built (yet),
- * -1 = too large. */
+/* Weighted spatial mode (calculate_tile_weights, entropy_utils.py:108-144) has three formulations:
+ *   0 table    direction weight table, built once per plan and gathered per distinct direction of a
+ *              frame (memory bound); 32-bit block-floating-point weights, 64-bit integer histograms
+ *   1 sweep    every sample sweeps every tile (FP64 VALU bound); 2^-52 fixed-point integer histograms
+ *   2 precise  the sweep with the exact weights in FP64 histograms, in the reference's summation order
+ * The integer formulations are order independent (bit-identical run to run, under any user
+ * permutation, frame split or GPU count).  They are only used where a bound computed from the plan's
+ * own rows proves their deviation from exact arithmetic <= 1e-7 relative for EVERY possible frame
+ * (k_row_stats; the contract is 1e-6); plans outside that — FoV cones narrower than the lattice
+ * spacing, large power factors — run `precise`.
+ * Which formulation a call uses is a pure function of the plan and the call's shape, never of the
+ * plan's history: policy 0 = table iff the call (or batch) holds >= 8 samples per direction of the
+ * plan's direction table, +1 = table whenever it is inside the contract and fits, -1 = never table.
+ * vet_plan_table_stride: row length of lattice k's table, 0 = not built (yet), -1 = does not fit.
+ * vet_plan_last_formulation: formulation lattice k used in the plan's last weighted call (-1 none).
+ * vet_plan_error_bounds: the proven relative entropy error bounds of lattice k for the table and the
+ * sweep (at <= 1024 users) formulations; inf = a frame exists whose entropy no fixed point resolves. */
 int vet_plan_set_table_policy(vet_plan *plan, int policy);
 int vet_plan_table_stride(const vet_plan *plan, int lattice);
+int vet_plan_last_formulation(const vet_plan *plan, int lattice);
+int vet_plan_error_bounds(vet_plan *plan, int lattice, double *table_bound, double *sweep_bound);
 /* Parity hooks: read back the device-built tables (synchronous). */
 int vet_plan_read_dirs(vet_plan *plan, double *h_xyz /* [n_dirs*3] rounded Vector xyz */);
 int vet_plan_read_nearest(vet_plan *plan, int lattice, int32_t *h_nearest /* [n_dirs] */);

@@ -1,0 +1,157 @@
+"""GPU: the 1e-6 RELATIVE entropy contract where it is hardest — frames of one or two users, whose
+entropy can be arbitrarily small — over the whole discrete sample domain (all 20 301 pixel directions),
+for EntropyConfigs whose weights span many orders of magnitude (narrow FoV, large power factor);
+degenerate lattices of 1-3 tiles; a BASELINE-config-4-shaped video.  Reference contract:
+utilities/entropy_utils.py:124-137 (weights), 194-209 (entropy and normaliser)."""
+import numpy as np
+import pytest
+
+from oracle import vet_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+W, H = 100, 200
+
+
+@pytest.fixture(scope="module")
+def native():
+    from viewport_entropy_toolkit import _native
+    return _native
+
+
+@pytest.fixture(scope="module")
+def engine(native):
+    return native.Engine.default()
+
+
+def all_directions():
+    """One sample per pixel direction: mu/mv that truncate to every (px, py) of the 101 x 201 grid."""
+    px, py = np.meshgrid(np.arange(W + 1), np.arange(H + 1))
+    px, py = px.ravel(), py.ravel()
+    mu = np.where(px == W, 1.0, (px + 0.5) / W)
+    mv = np.where(py == H, 1.0, (py + 0.5) / H)
+    return mu, mv
+
+
+EXTREME = [([50], 30.0, 2.0), ([50], 120.0, 20.0), ([500], 5.0, 3.0), ([500], 10.0, 2.0), ([50], 120.0, 50.0)]
+_ORACLE = {}
+
+
+def contract_cases():
+    mu1, mv1 = all_directions()
+    rng = np.random.default_rng(20301)
+    perm = rng.permutation(len(mu1))
+    near = (np.arange(len(mu1)) + 1) % len(mu1)                # neighbouring pixel: overlapping cones
+    return {
+        "one user": (mu1[:, None], mv1[:, None]),
+        "two users, random pair": (np.stack([mu1, mu1[perm]], 1), np.stack([mv1, mv1[perm]], 1)),
+        "two users, neighbours": (np.stack([mu1, mu1[near]], 1), np.stack([mv1, mv1[near]], 1)),
+    }
+
+
+def oracle_for(tcs, fov, power, name, mu, mv):
+    key = (tuple(tcs), fov, power, name)
+    if key not in _ORACLE:
+        _ORACLE[key] = vo.spatial_series(mu, mv, W, H, tcs, fov_angle=fov, power_factor=power)[:2]
+    return _ORACLE[key]
+
+
+@pytest.mark.parametrize("tcs,fov,power", EXTREME + [([500], 120.0, 2.0), ([20, 50], 120.0, 2.0)])
+@pytest.mark.parametrize("policy", [1, -1, 0])
+def test_single_and_two_user_frames_over_all_directions(native, engine, tcs, fov, power, policy):
+    cases = contract_cases()
+    plan = native.Plan(engine, [vo.fibonacci_lattice(tc) for tc in tcs], fov, power, True, W, H)
+    plan.set_table_policy(policy)
+    tab_bound, sweep_bound = plan.error_bounds(0)
+    for name, (mu, mv) in cases.items():
+        res = plan.spatial(mu=mu, mv=mv)
+        form = plan.last_formulation(0)
+        if (tcs, fov, power) in EXTREME[:2] + EXTREME[3:]:
+            assert form == "precise", (name, form, tab_bound, sweep_bound)    # integers cannot hold these
+        ent, assign = oracle_for(tcs, fov, power, name, mu, mv)
+        assert np.array_equal(res["assign"], assign), name
+        assert np.array_equal(np.isnan(res["entropy"]), np.isnan(ent)), name
+        ok = ~np.isnan(ent)
+        np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=1e-6, atol=0, err_msg=f"{name} [{form}]")
+    plan.close()
+
+
+@pytest.mark.parametrize("tcs", [[1], [2], [3], [1, 3], [3, 50]])
+@pytest.mark.parametrize("policy", [1, -1, 0])
+@pytest.mark.parametrize("fov,power", [(120.0, 2.0), (30.0, 0.5), (360.0, 1.0)])
+def test_degenerate_lattices(native, engine, tcs, policy, fov, power):
+    """1-, 3- and 3-tile lattices (tile_count 1, 2, 3 -> n = 1, 3, 3): frames whose users weigh on one tile
+    only, frames where nobody has a tile in the FoV, the 0 / -0.0 normaliser of a one-tile lattice; the
+    nan / 0.0 pattern must be the reference's."""
+    rng = np.random.default_rng(sum(tcs) * 7 + int(fov))
+    U, T = 61, 48
+    mu, mv = rng.random((T, U)), rng.random((T, U))
+    gone = rng.random((T, U)) < 0.3
+    gone[:, 0] = False
+    mu[gone] = np.nan
+    mv[gone] = np.nan
+    mu[:8, 1:] = np.nan                     # single-user frames
+    mv[:8, 1:] = np.nan
+    plan = native.Plan(engine, [vo.fibonacci_lattice(tc) for tc in tcs], fov, power, True, W, H)
+    plan.set_table_policy(policy)
+    res = plan.spatial(mu=mu, mv=mv, want_weights=True)
+    ent, assign, weights = vo.spatial_series(mu, mv, W, H, tcs, fov_angle=fov, power_factor=power, want_weights=True)
+    assert np.array_equal(res["assign"], assign)
+    assert np.array_equal(np.isnan(res["entropy"]), np.isnan(ent)), (res["entropy"][:10], ent[:10])
+    ok = ~np.isnan(ent)
+    np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=1e-6, atol=0)
+    np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=2.0 ** -33 * U)
+    plan.close()
+
+
+@pytest.mark.parametrize("policy", [1, -1, 0])
+def test_config4_shape(native, engine, policy):
+    """BASELINE config 4, one GPU's share: 256 users x 10 000 frames, tile_counts=[50,100,200]: run-to-run
+    bit equality, invariance under user permutation and frame split (integer histograms), nearest == LUT,
+    sampled frames against the oracle."""
+    U, T, tcs = 256, 10000, [50, 100, 200]
+    rng = np.random.default_rng(44)
+    mu = np.mod(0.5 + np.cumsum(rng.normal(0, 0.01, (T, U)), axis=0), 1.0)
+    mv = np.clip(0.5 + np.cumsum(rng.normal(0, 0.005, (T, U)), axis=0), 0.0, 1.0)
+    plan = native.Plan(engine, [vo.fibonacci_lattice(tc) for tc in tcs], 120.0, 2.0, True, W, H)
+    plan.set_table_policy(policy)
+    a = plan.spatial(mu=mu, mv=mv, want_assign=True, want_weights=True)
+    assert plan.last_formulation(0) == ("sweep" if policy < 0 else "table")
+    b = plan.spatial(mu=mu, mv=mv, want_assign=False)
+    assert np.array_equal(a["entropy"], b["entropy"])
+    assert np.all(np.isfinite(a["entropy"])) and a["entropy"].min() > 0 and a["entropy"].max() <= 1.0
+    perm = rng.permutation(U)
+    c = plan.spatial(mu=mu[:, perm], mv=mv[:, perm], want_assign=False)
+    assert np.array_equal(c["entropy"], a["entropy"])
+    d = plan.spatial(mu=mu[3333:7001], mv=mv[3333:7001], want_assign=False)
+    if policy != 0:                      # under policy 0 the shorter call is still a table call (8 x 20 301 samples)
+        assert np.array_equal(d["entropy"], a["entropy"][3333:7001])
+    else:
+        np.testing.assert_allclose(d["entropy"], a["entropy"][3333:7001], rtol=1e-8)
+    near = plan.read_nearest(0).reshape(H + 1, W + 1)
+    assert np.array_equal(a["assign"], near[(mv * H).astype(int), (mu * W).astype(int)])
+    frames = np.concatenate([[0, T - 1], rng.integers(0, T, 30)])
+    ent, assign, weights = vo.spatial_series(mu[frames], mv[frames], W, H, tcs, want_weights=True)
+    assert np.array_equal(a["assign"][frames], assign)
+    np.testing.assert_allclose(a["entropy"][frames], ent, rtol=1e-8)
+    np.testing.assert_allclose(a["weights"][frames], weights, rtol=1e-9, atol=2.0 ** -33 * U + 1e-12)
+    plan.close()
+
+
+def test_error_bounds_of_the_baseline_plans(native, engine):
+    """The BASELINE configurations (fov 120, power 2, lattices of 21 ... 1001 tiles) are provably inside the
+    contract with integer histograms; narrow cones and large powers are not."""
+    plan = native.Plan(engine, [vo.fibonacci_lattice(tc) for tc in (20, 50, 100, 200, 250, 500, 1000)], 120.0, 2.0,
+                       True, W, H)
+    for k in range(7):
+        tab, sweep = plan.error_bounds(k)
+        assert 0 < tab <= 1e-7 and 0 < sweep <= 1e-7, (k, tab, sweep)
+    plan.close()
+    for tcs, fov, power in EXTREME:
+        plan = native.Plan(engine, [vo.fibonacci_lattice(tc) for tc in tcs], fov, power, True, W, H)
+        tab, sweep = plan.error_bounds(0)
+        if (tcs, fov, power) == ([500], 5.0, 3.0):
+            assert tab == np.inf and sweep == np.inf          # every row has at most one tile in its FoV
+        else:
+            assert tab > 1e-7
+        plan.close()

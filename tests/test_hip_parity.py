@@ -12,14 +12,24 @@ pytestmark = pytest.mark.gpu
 
 RTOL = 1e-9          # contract is 1e-6; the fixed-point histogram + FP64 entropy sits near 1e-13
 ATOL_W = 1e-12       # absolute tolerance on tile weight sums (fixed point resolution 2^-52 per add)
-# Weighted mode has two formulations (include/vet.h, vet_plan_set_table_policy): brute-force
-# sweep (-1) and direction weight table (+1, u32 fixed point: 2^-33 abs per weight).
+# Weighted mode (include/vet.h, vet_plan_set_table_policy): brute-force sweep (-1) and direction weight
+# table (+1: u32 mantissas below each row's largest weight, at most 2^-33 abs per weight); plans whose
+# error bound is outside the contract run the FP64 'precise' formulation under either policy.
 POLICIES = [pytest.param(-1, id="sweep"), pytest.param(1, id="table")]
 
 
 def tol(policy, users=1):
     """(entropy rtol, weight-sum atol) per formulation."""
     return (RTOL, ATOL_W) if policy < 0 else (1e-8, 2.0 ** -33 * users + ATOL_W)
+
+
+def expected_formulation(plan, policy, lattice=0):
+    """What the plan must have run: the requested integer formulation, or 'precise' where the plan's own
+    error bound says integers are outside the contract."""
+    tab, sweep = plan.error_bounds(lattice)
+    if policy > 0 and tab <= 1e-7:
+        return "table"
+    return "sweep" if sweep <= 1e-7 else "precise"
 
 
 @pytest.fixture(scope="module")
@@ -105,7 +115,7 @@ def test_spatial_vs_reference_goldens(native, engine, golden_dir, tag, tcs, kw, 
     plan = make_plan(native, engine, tcs, policy=policy, **kw)
     res = plan.spatial(mu=mu, mv=mv, want_assign=True, want_weights=True)
     if kw.get("weighted", True):
-        assert (plan.table_stride(0) > 0) == (policy > 0)
+        assert plan.last_formulation(0) == expected_formulation(plan, policy)
     rtol, atol = tol(policy, mu.shape[1])
     assert np.array_equal(res["assign"], g[f"{tag}__assign"])
     np.testing.assert_allclose(res["entropy"], g[f"{tag}__entropy"], rtol=rtol, equal_nan=True)
@@ -186,8 +196,9 @@ def test_weight_rows_vs_reference(native, engine, golden_dir, policy):
         res = plan.spatial(mu=mu, mv=mv, want_weights=True)
         ref = g[f"{tag}__rows"]
         np.testing.assert_allclose(res["weights"], ref, rtol=1e-9, atol=1e-15 if policy < 0 else 2.0 ** -33)
-        if policy > 0:      # rows hold exactly the tiles the reference's dict holds
-            assert np.array_equal(res["weights"] > 0, ref >= 2.0 ** -33)
+        if policy > 0:      # rows hold the tiles the reference's dict holds (down to 2^-33 of the row's largest weight)
+            assert not ((res["weights"] > 0) & ~(ref > 0)).any()
+            assert not ((ref >= 2.0 ** -33) & ~(res["weights"] > 0)).any()
         assert np.array_equal(res["assign"][:, 0], g[f"{tag}__nearest"])
         plan.close()
 
@@ -219,7 +230,7 @@ def test_config2_vs_oracle(native, engine, weighted, policy):
     plan = make_plan(native, engine, tcs, weighted=weighted, policy=policy)
     res = plan.spatial(mu=mu, mv=mv, want_weights=True)
     if weighted and policy == 0:
-        assert plan.table_stride(0) == 0         # 192 000 samples < 16 x 20 301 directions: one call sweeps
+        assert plan.last_formulation(0) == "table"      # 192 000 samples >= 8 x 20 301 directions
     ent, assign, weights = vo.spatial_series(mu, mv, 100, 200, tcs, use_weight_distribution=weighted,
                                              want_weights=True)
     rtol, atol = tol(1 if policy > 0 else -1, 64)
@@ -361,16 +372,27 @@ def test_config5_transition_full_size_properties(native, engine):
     plan.close()
 
 
-def test_auto_policy_builds_tables_once_a_plan_has_seen_enough_samples(native, engine):
-    """Small videos sweep; a plan reused for many of them switches to the table (same results)."""
+def test_formulation_is_a_pure_function_of_the_call(native, engine):
+    """Policy 0 picks table or sweep from the call's shape alone: a small video sweeps however many
+    videos the plan has seen and whether or not its tables exist, a large one gathers, and the same
+    input returns the same floats before and after."""
     from viewport_entropy_toolkit import _synthetic
     plan = make_plan(native, engine, [50, 100], policy=0)
-    outs = []
-    for v in range(140):                                  # 140 x 2400 samples > 16 x 20 301 directions
-        mu, mv = _synthetic.random_walk_video(8, 300, base_seed=5, video_id=v)
-        outs.append((mu, mv, plan.spatial(mu=mu, mv=mv)["entropy"], plan.table_stride(0) > 0))
-    assert not outs[0][3] and outs[-1][3]
-    for mu, mv, ent, _ in (outs[0], outs[-1]):
+    small = _synthetic.random_walk_video(8, 300, base_seed=5)
+    big = _synthetic.random_walk_video(96, 2000, base_seed=6)          # 192 000 samples >= 8 x 20 301
+    first = plan.spatial(mu=small[0], mv=small[1])["entropy"]
+    assert plan.last_formulation(0) == "sweep" and plan.table_stride(0) == 0
+    for v in range(80):
+        mu, mv = _synthetic.random_walk_video(8, 300, base_seed=5, video_id=v + 1)
+        plan.spatial(mu=mu, mv=mv)
+    assert plan.last_formulation(0) == "sweep" and plan.table_stride(0) == 0
+    e_big = plan.spatial(mu=big[0], mv=big[1])["entropy"]
+    assert plan.last_formulation(0) == "table" and plan.table_stride(0) > 0
+    again = plan.spatial(mu=small[0], mv=small[1])["entropy"]
+    assert plan.last_formulation(0) == "sweep"
+    assert np.array_equal(first, again)
+    assert np.array_equal(e_big, plan.spatial(mu=big[0], mv=big[1])["entropy"])
+    for (mu, mv), ent in ((small, first), (big, e_big)):
         ref, _, _ = vo.spatial_series(mu, mv, 100, 200, [50, 100])
         np.testing.assert_allclose(ent, ref, rtol=1e-8)
     plan.close()

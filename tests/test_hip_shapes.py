@@ -143,10 +143,11 @@ def test_extreme_entropy_configs(native, engine, fov, power, policy):
     ent, assign, weights = vo.spatial_series(mu, mv, 100, 200, [100, 20], fov_angle=fov, power_factor=power,
                                              want_weights=True)
     assert np.array_equal(res["assign"], assign)
-    # the table stores w * 2^32 (saturating at 1 - 2^-32): 2^-32 absolute per weight
+    # the table stores 32-bit mantissas below the row's largest weight: at most 2^-32 absolute per weight
     np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=2.0 ** -32 * 60 + 1e-12)
+    assert np.array_equal(np.isnan(res["entropy"]), np.isnan(ent))
     ok = np.isfinite(ent)
-    np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=2e-7 if power > 10 else 1e-8, atol=1e-12)
+    np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=1e-8, atol=0)
     plan.close()
 
 
@@ -171,11 +172,6 @@ def test_cabi_argument_validation(native, engine):
     # ids beyond the direction table are flagged like out-of-range samples
     res = plan.spatial(ids=np.array([[0, 5, 10 ** 7]], dtype=np.int32), check=False)
     assert res["code"] == native.VET_ERR_RANGE
-    # transition with more users than the LDS hash can hold is refused, not wrong
-    big = np.full((2, 9000), 0.5)
-    with pytest.raises(native.NativeError) as ei:
-        plan.transition(mu=big, mv=big)
-    assert ei.value.code == native.VET_ERR_UNSUPPORTED
     plan.close()
 
 

@@ -13,7 +13,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -77,9 +79,15 @@ struct Lattice {
     double hmax = 0.0;
     // direction weight table (ELL), built on first use when the video has more samples than the
     // plan has directions
-    uint32_t* d_tab_w = nullptr;   // [n_dirs][stride]
-    uint16_t* d_tab_i = nullptr;   // [n_dirs][stride]
-    uint16_t* d_tab_len = nullptr; // [n_dirs]
+    uint32_t* d_tab_w = nullptr;   // [n_dirs+1][stride] u32 mantissas (block floating point per row)
+    uint16_t* d_tab_i = nullptr;   // [n_dirs+1][stride]
+    uint32_t* d_tab_meta = nullptr;// [n_dirs+1] entries in use | row shift << 16
+    uint8_t* d_row_s = nullptr;    // [n_dirs+1] row shift (k_row_stats)
+    // k_row_stats: worst-case relative entropy error of integer histograms over every possible frame
+    bool stats_done = false;
+    double crit_tab = 0.0;         // table formulation (step 2^(e_row - 33) per entry)
+    double crit_base = 0.0;        // times the step of the sweep formulation
+    int last_form = -1;            // formulation of the last weighted call (parity / bench introspection)
     int stride = 0;                // 0 = not built, -1 = not usable (too large)
     int gs_log2 = 4;               // lanes per gather group (log2); fixed when the table is built
     bool interleaved = false;      // well-filled row blocks are dealt by LDS bank class (k_wtab)
@@ -98,9 +106,8 @@ struct vet_plan {
     double fov = 120.0, max_ang = 0.0, power = 2.0;
     int weighted = 1;
     double cos_cull = 0.0;
-    int table_policy = 0;          // 0 auto, 1 always use the weight table, -1 never
-    long samples_seen = 0;         // samples this plan has processed (auto policy: tables pay off
-                                   // once a plan has seen 16 samples per direction, want_table)
+    int table_policy = 0;          // 0 by call size, 1 table whenever it is inside the contract, -1 never
+    uint32_t* d_alias = nullptr;   // [n_dirs] direction id -> first id with the same Vector
 };
 
 namespace {
@@ -226,52 +233,145 @@ int weight_mode(const vet_plan* pl) {
 }
 
 template <bool FROM_IDS>
-const void* spatial_w_kernel(int wmode, int R) {
-#define VET_PICK(W, RR) if (wmode == W && R == RR) return (const void*)vet::k_spatial_w<FROM_IDS, W, RR>
+const void* spatial_w_kernel(int wmode, int R, bool precise = false) {
+    if (precise) return R == 1 ? (const void*)vet::k_spatial_w<FROM_IDS, 0, 1, true> : (const void*)vet::k_spatial_w<FROM_IDS, 0, 2, true>;
+#define VET_PICK(W, RR) if (wmode == W && R == RR) return (const void*)vet::k_spatial_w<FROM_IDS, W, RR, false>
     VET_PICK(0, 1); VET_PICK(0, 2); VET_PICK(1, 1); VET_PICK(1, 2); VET_PICK(2, 1); VET_PICK(2, 2);
 #undef VET_PICK
     return nullptr;
 }
 
+template <bool FROM_IDS>
+const void* lut_kernel(bool il, bool occ8, bool dedup) {
+#define VET_PICK(I, O, D) if (il == I && occ8 == O && dedup == D) return (const void*)vet::k_spatial_lut<FROM_IDS, 2, I, O, D>
+    VET_PICK(false, false, false); VET_PICK(false, true, false); VET_PICK(true, false, false); VET_PICK(true, true, false);
+    VET_PICK(false, false, true); VET_PICK(false, true, true); VET_PICK(true, false, true); VET_PICK(true, true, true);
+#undef VET_PICK
+    return nullptr;
+}
+
 constexpr size_t kMaxTableBytes = (size_t)24 << 30;   // per lattice; HBM is 288 GB
+constexpr double kContractMargin = 1e-7;              // bound on |dH|/H an integer formulation may have (contract: 1e-6)
+
+// direction id -> first id with the same Vector (value equality, -0.0 == 0.0): the pole row of a pixel
+// grid, the -180 -> 0 / -90 -> 0 remaps (utilities/data_utils.py:394-397) and 6-decimal collisions make
+// different pixels the same direction; they share one table row.
+int ensure_alias(vet_plan* pl) {
+    if (pl->d_alias) return VET_OK;
+    const size_t D = (size_t)pl->n_dirs;
+    std::vector<double> raw(D * 3);
+    HIP_TRY(hipMemcpy(raw.data(), pl->d_dir_raw, D * 24, hipMemcpyDeviceToHost));
+    struct KeyHash {
+        size_t operator()(const std::array<uint64_t, 3>& k) const {
+            uint64_t h = k[0] * 0x9E3779B97F4A7C15ull;
+            h ^= (k[1] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2));
+            h ^= (k[2] * 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2));
+            return (size_t)h;
+        }
+    };
+    std::unordered_map<std::array<uint64_t, 3>, uint32_t, KeyHash> first;
+    first.reserve(D * 2);
+    std::vector<uint32_t> alias(D);
+    for (size_t d = 0; d < D; ++d) {
+        std::array<uint64_t, 3> key;
+        for (int c = 0; c < 3; ++c) {
+            const double v = raw[3 * d + c] + 0.0;          // -0.0 -> +0.0
+            memcpy(&key[c], &v, 8);
+        }
+        alias[d] = first.emplace(key, (uint32_t)d).first->second;
+    }
+    HIP_TRY(hipMalloc((void**)&pl->d_alias, D * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(pl->d_alias, alias.data(), D * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return VET_OK;
+}
+
+// k_row_stats of lattice k (first weighted run only; synchronises once)
+int ensure_stats(vet_plan* pl, int k, hipStream_t s) {
+    Lattice& L = pl->lat[k];
+    if (L.stats_done) return VET_OK;
+    vet_ctx* c = pl->ctx;
+    unsigned long long* d_crit = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_crit, 16));
+    if (!L.d_row_s && hipMalloc((void**)&L.d_row_s, (size_t)pl->n_dirs + 1) != hipSuccess) {
+        (void)hipFree(d_crit);
+        return fail(VET_ERR_DEVICE, "hipMalloc of the row shift table failed");
+    }
+    hipError_t e = hipMemsetAsync(d_crit, 0, 16, s);
+    vet::StatsParams p;
+    p.dir_unit = pl->d_dir_unit; p.D = (long)pl->n_dirs;
+    p.tiles = L.d_tiles; p.n = L.n;
+    p.cos_cull = pl->cos_cull;
+    p.wc.max_ang = pl->max_ang; p.wc.inv_max = 1.0 / pl->max_ang; p.wc.power = pl->power; p.wc.shift = 0;
+    p.row_s = L.d_row_s; p.crit = d_crit;
+    const int blocks = grid_for((long)pl->n_dirs * vet::WAVE, 256, c->n_cu * 2);
+    {
+        ProfScope ps(c, s, KID_WTAB);
+        hipLaunchKernelGGL(vet::k_row_stats, dim3(blocks), dim3(256), 0, s, p);
+    }
+    unsigned long long bits[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(bits, d_crit, 16, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_crit);
+    if (e != hipSuccess) return fail(VET_ERR_DEVICE, "k_row_stats failed: %s", hipGetErrorString(e));
+    memcpy(&L.crit_tab, &bits[0], 8);
+    memcpy(&L.crit_base, &bits[1], 8);
+    L.stats_done = true;
+    return VET_OK;
+}
 
 // Builds lattice k's direction weight table on stream s (first use only; synchronises once).
+// A table that does not fit (size cap, allocation failure) marks the lattice stride = -1: the plan then
+// stays on the sweep formulation.
 int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     Lattice& L = pl->lat[k];
     if (L.stride != 0) return VET_OK;
     vet_ctx* c = pl->ctx;
+    int rc = ensure_stats(pl, k, s);
+    if (rc) return rc;
+    rc = ensure_alias(pl);
+    if (rc) return rc;
     int* d_max = nullptr;
     HIP_TRY(hipMalloc((void**)&d_max, sizeof(int)));
-    HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(int), s));
+    hipError_t e = hipMemsetAsync(d_max, 0, sizeof(int), s);
     vet::WtabParams p;
     p.dir_unit = pl->d_dir_unit; p.D = (long)pl->n_dirs;
     p.tiles = L.d_tiles; p.n = L.n;
     p.cos_cull = pl->cos_cull;
     p.wc.max_ang = pl->max_ang; p.wc.inv_max = 1.0 / pl->max_ang; p.wc.power = pl->power; p.wc.shift = 0;
-    p.stride = 0; p.w = nullptr; p.idx = nullptr; p.len = nullptr; p.maxcount = d_max; p.gs_log2 = -1;
+    p.stride = 0; p.w = nullptr; p.idx = nullptr; p.meta = nullptr; p.row_s = L.d_row_s; p.maxcount = d_max; p.gs_log2 = -1;
     const int blocks = grid_for((long)pl->n_dirs * vet::WAVE, 256, c->n_cu * 2);
     {
         ProfScope ps(c, s, KID_WTAB);
         hipLaunchKernelGGL(vet::k_wtab<false>, dim3(blocks), dim3(256), 0, s, p);
     }
     int longest = 0;
-    hipError_t e = hipMemcpyAsync(&longest, d_max, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&longest, d_max, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(d_max);
     if (e != hipSuccess) return fail(VET_ERR_DEVICE, "k_wtab<count> failed: %s", hipGetErrorString(e));
     int align = 64;      // rows start on 128-byte lines (u16 tile rows) / 256 bytes (u32 weight rows)
     align = (env_int("VET_STRIDE_ALIGN", 64, 1024, align) + 63) / 64 * 64;   // whole 64-entry blocks: the walk reads whole blocks
     int stride = ((longest > 0 ? longest : 1) + align - 1) / align * align;
-    const size_t bytes = (size_t)pl->n_dirs * stride * 6;
-    if (bytes > kMaxTableBytes) { L.stride = -1; return VET_OK; }
+    const size_t rows = (size_t)pl->n_dirs + 1;   // one extra, all-zero row (index n_dirs) for the gather's idle lanes
+    const size_t bytes = rows * stride * 6 + rows * 4;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = kMaxTableBytes;
+    if (stride > 65535 || bytes > kMaxTableBytes || bytes + ((size_t)64 << 20) > free_b) { L.stride = -1; return VET_OK; }
     // a failed earlier attempt may have left buffers behind
-    if (L.d_tab_w) { (void)hipFree(L.d_tab_w); L.d_tab_w = nullptr; }
-    if (L.d_tab_i) { (void)hipFree(L.d_tab_i); L.d_tab_i = nullptr; }
-    if (L.d_tab_len) { (void)hipFree(L.d_tab_len); L.d_tab_len = nullptr; }
-    // one extra, all-zero row (index n_dirs) for the gather's idle lanes
-    HIP_TRY(hipMalloc((void**)&L.d_tab_w, (size_t)(pl->n_dirs + 1) * stride * 4));
-    HIP_TRY(hipMalloc((void**)&L.d_tab_i, (size_t)(pl->n_dirs + 1) * stride * 2));
-    HIP_TRY(hipMalloc((void**)&L.d_tab_len, (size_t)(pl->n_dirs + 1) * 2));
+    auto drop = [&]() {
+        if (L.d_tab_w) { (void)hipFree(L.d_tab_w); L.d_tab_w = nullptr; }
+        if (L.d_tab_i) { (void)hipFree(L.d_tab_i); L.d_tab_i = nullptr; }
+        if (L.d_tab_meta) { (void)hipFree(L.d_tab_meta); L.d_tab_meta = nullptr; }
+    };
+    drop();
+    if (hipMalloc((void**)&L.d_tab_w, rows * stride * 4) != hipSuccess ||
+        hipMalloc((void**)&L.d_tab_i, rows * stride * 2) != hipSuccess ||
+        hipMalloc((void**)&L.d_tab_meta, rows * 4) != hipSuccess) {
+        (void)hipGetLastError();                  // out of memory is not sticky: the sweep still works
+        drop();
+        L.stride = -1;
+        return VET_OK;
+    }
     // 4 entries per lane and 2 rows in flight per group; lanes per row (part of the row layout) = the
     // smallest power of two whose 4-entry chunks cover the longest row, at most 16 (measured best for
     // long rows, profiles/r01/v4_table_vs_xcd_partition_sweep.log), so the short rows of small
@@ -282,7 +382,7 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     // 16-lane rows with at least one block that is 3/4 full get the class-dealt layout (k_wtab)
     L.interleaved = L.gs_log2 == 4 && stride % 64 == 0 && 4 * longest >= 3 * 64;
     L.interleaved = L.interleaved && env_int("VET_TAB_INTERLEAVE", 0, 1, 1) != 0;
-    p.stride = stride; p.w = L.d_tab_w; p.idx = L.d_tab_i; p.len = L.d_tab_len; p.maxcount = nullptr;
+    p.stride = stride; p.w = L.d_tab_w; p.idx = L.d_tab_i; p.meta = L.d_tab_meta; p.maxcount = nullptr;
     p.gs_log2 = L.interleaved ? L.gs_log2 : -1;
     {
         ProfScope ps(c, s, KID_WTAB);
@@ -315,15 +415,115 @@ bool any_binned(const vet_plan* pl) {
     return false;
 }
 
-bool want_table(const vet_plan* pl, int U, int T) {
-    if (!pl->weighted || pl->table_policy < 0 || any_binned(pl)) return false;
-    if (pl->table_policy > 0) return true;
-    // Tables exist already, or they pay for themselves: building a row costs about 30 times what
-    // the sweep spends on one sample (k_wtab evaluates acos/pow for a whole row; measured 0.27 ms per
-    // 20 301 x 501 table vs 11.9 ms per 30.72 M x 501 sweep), and a gathered sample is ~6x cheaper
-    // than a swept one, so switch once the plan has seen 16 samples per direction.
-    if (pl->lat[0].stride > 0) return true;
-    return pl->samples_seen + (long)U * T >= 16 * (long)pl->n_dirs;
+// The formulation of a weighted call is a pure function of the plan and the call's shape — never of
+// what the plan has processed before — so the same input always gives the same floats:
+//   table    policy +1, or policy 0 and the call holds at least 8 samples per direction of the table
+//            (building a row costs about what the sweep spends on 30 samples; a gathered sample is ~6x
+//            cheaper than a swept one), if the table fits and its error bound is inside the contract;
+//   sweep    integer (2^-52) histogram, if its error bound is inside the contract;
+//   precise  FP64 histogram and exact weights otherwise.
+enum { F_TABLE = 0, F_SWEEP = 1, F_PRECISE = 2 };
+
+bool table_requested(const vet_plan* pl, long samples, int U) {
+    if (!pl->weighted || pl->table_policy < 0 || any_binned(pl) || U >= 65536) return false;
+    if ((int)pl->lat.size() > vet::MAX_LATTICES) return false;
+    return pl->table_policy > 0 || samples >= 8 * (long)pl->n_dirs;
+}
+
+int sweep_shift(int U) {
+    int ubits = 0;
+    while ((1L << ubits) < (long)U) ++ubits;
+    return ubits > 10 ? ubits - 10 : 0;      // per-tile sums of U weights stay below 2^62
+}
+
+// integer sweep if its error bound is inside the contract, FP64 sweep otherwise
+int sweep_formulation(const vet_plan* pl, const Lattice& L, int U) {
+    // the sweep truncates at 2^(shift-52); its fast arc cosine (fov <= 120, power 1 or 2) is good to 4e-14
+    double step = std::ldexp(1.0, sweep_shift(U) - 52);
+    if (weight_mode(pl) != 0 && step < 4e-14) step = 4e-14;
+    return L.crit_base * step <= kContractMargin ? F_SWEEP : F_PRECISE;
+}
+
+// formulation of lattice k for a call; builds the statistics (and the table) on first use
+int choose_formulation(vet_plan* pl, int k, bool want_table, int U, hipStream_t s, int* out) {
+    Lattice& L = pl->lat[k];
+    int rc = ensure_stats(pl, k, s);
+    if (rc) return rc;
+    if (want_table && L.crit_tab <= kContractMargin) {
+        rc = ensure_wtab(pl, k, s);
+        if (rc) return rc;
+        if (L.stride > 0) { *out = F_TABLE; return VET_OK; }
+    }
+    *out = sweep_formulation(pl, L, U);
+    return VET_OK;
+}
+
+// one launch of the table kernel over lattices lat_idx[0..K) of the plan (single video or a batch)
+template <bool FROM_IDS>
+int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& src, int U, int T,
+               const vet::VideoDesc* d_videos, int n_videos, int blocks_batch, size_t lds_batch,
+               double* d_entropy, int32_t* d_assign, double* d_weights, int32_t* d_present, int32_t* d_status,
+               hipStream_t s, bool* launched) {
+    vet_ctx* c = pl->ctx;
+    *launched = false;
+    vet::LutParams q;
+    q.videos = d_videos; q.n_videos = n_videos;
+    q.src = src; q.U = U; q.T = T;
+    q.nearest = pl->lat[lat_idx[0]].d_nearest;
+    q.alias = pl->d_alias;
+    q.K = K; q.n_sum = 0;
+    bool il = false;
+    for (int k = 0; k < K; ++k) {
+        const Lattice& L = pl->lat[lat_idx[k]];
+        q.lat[k].tab_w = L.d_tab_w; q.lat[k].tab_i = L.d_tab_i; q.lat[k].tab_meta = L.d_tab_meta;
+        q.lat[k].stride = L.stride;
+        q.lat[k].gs_log2 = L.gs_log2; q.lat[k].interleaved = L.interleaved ? 1 : 0;
+        q.lat[k].n = L.n; q.lat[k].hmax = L.hmax;
+        q.n_sum += L.n;
+        il = il || L.interleaved;
+    }
+    q.entropy = d_entropy; q.assign = d_assign; q.weights = d_weights; q.present = d_present;
+    q.status = d_status;
+    const bool dedup = (uint64_t)pl->n_dirs <= vet::DEDUP_MAX_DIRS && !getenv("VET_NO_DEDUP");
+    int blocks = blocks_batch, threads = 256;
+    size_t lds = lds_batch;
+    bool occ8 = true;
+    if (!d_videos) {
+        q.UC = U < 2048 ? U : 2048;
+        int fpw = lut_frames_per_wg(U, T, c->n_cu, q.n_sum);
+        fpw = env_int("VET_LUT_FPW", 1, 16, fpw);
+        for (;; fpw /= 2) {
+            lds = vet::lut_lds_bytes(U, q.UC, fpw, q.n_sum, dedup);
+            if (lds <= c->lds_max || fpw == 1) break;
+        }
+        if (lds > c->lds_max) return VET_OK;      // not launched: caller falls back to the sweep
+        q.FPW = fpw;
+        blocks = (T + fpw - 1) / fpw;
+        threads = env_threads("VET_LUT_THREADS", threads);
+        occ8 = K == 1 && threads == 256;
+    } else {
+        q.FPW = 1; q.UC = 1;
+    }
+    ProfScope ps(c, s, KID_SPATIAL);
+    void* args[] = {(void*)&q};
+    // 2 rows in flight per lane group measured best (4 and 8 were tried, profiles/r01/v3_*)
+    HIP_TRY(hipLaunchKernel(lut_kernel<FROM_IDS>(il, occ8, dedup), dim3((unsigned)blocks), dim3(threads), args, lds, s));
+    HIP_TRY(hipGetLastError());
+    *launched = true;
+    return VET_OK;
+}
+
+// LDS bytes and frames per workgroup of one video of a batch (0 = does not fit)
+size_t batch_video_geometry(const vet_ctx* c, int U, long total_frames, int n_sum, bool dedup, int* fpw_out, int* uc_out) {
+    const int UC = U < 2048 ? U : 2048;
+    int fpw = lut_frames_per_wg(U, total_frames, c->n_cu, n_sum);
+    size_t lds = 0;
+    for (;; fpw /= 2) {
+        lds = vet::lut_lds_bytes(U, UC, fpw, n_sum, dedup);
+        if (lds <= c->lds_max || fpw == 1) break;
+    }
+    *fpw_out = fpw; *uc_out = UC;
+    return lds <= c->lds_max ? lds : 0;
 }
 
 template <bool FROM_IDS>
@@ -332,59 +532,29 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
     vet_ctx* c = pl->ctx;
     const int K = (int)pl->lat.size();
     double* ent_k = d_entropy;
-    int ubits = 0;
-    while ((1L << ubits) < (long)U) ++ubits;
-    struct Seen { vet_plan* p; long n; ~Seen() { p->samples_seen += n; } } seen{pl, (long)U * T};
-    // ---- weighted, table formulation: every lattice in one launch
-    if (want_table(pl, U, T) && K <= vet::MAX_LATTICES) {
-        bool ok = true;
-        for (int k = 0; k < K; ++k) {
-            int rc = ensure_wtab(pl, k, s);
+    // ---- formulation per lattice (weighted Fibonacci lattices only)
+    int form[64];
+    if (K > 64) return fail(VET_ERR_UNSUPPORTED, "more than 64 lattices in one plan");
+    const bool want_table = table_requested(pl, (long)U * T, U);
+    bool all_table = pl->weighted != 0;
+    for (int k = 0; k < K; ++k) {
+        form[k] = F_SWEEP;
+        if (pl->weighted && !pl->lat[k].binned) {
+            int rc = choose_formulation(pl, k, want_table, U, s, &form[k]);
             if (rc) return rc;
-            ok = ok && pl->lat[k].stride > 0;
         }
-        if (ok) {
-            vet::LutParams q;
-            q.videos = nullptr; q.n_videos = 0;
-            q.src = src; q.U = U; q.T = T;
-            q.nearest = pl->lat[0].d_nearest;
-            q.K = K; q.n_sum = 0;
-            for (int k = 0; k < K; ++k) {
-                const Lattice& L = pl->lat[k];
-                q.lat[k].tab_w = L.d_tab_w; q.lat[k].tab_i = L.d_tab_i; q.lat[k].tab_len = L.d_tab_len;
-                q.lat[k].stride = L.stride;
-                q.lat[k].gs_log2 = L.gs_log2; q.lat[k].interleaved = L.interleaved ? 1 : 0;
-                q.lat[k].n = L.n; q.lat[k].hmax = L.hmax;
-                q.n_sum += L.n;
-            }
-            q.entropy = d_entropy; q.assign = d_assign; q.weights = d_weights; q.present = d_present;
-            q.status = d_status;
-            q.UC = U < 2048 ? U : 2048;
-            int fpw = lut_frames_per_wg(U, T, c->n_cu, q.n_sum);
-            fpw = env_int("VET_LUT_FPW", 1, 16, fpw);
-            size_t lds = 0;
-            for (;; fpw /= 2) {
-                lds = (size_t)fpw * q.n_sum * 8 + (size_t)fpw * q.UC * 6 + (size_t)2 * fpw * 4 + 64;
-                if (lds <= c->lds_max || fpw == 1) break;
-            }
-            if (lds <= c->lds_max) {
-                q.FPW = fpw;
-                const int blocks = (T + fpw - 1) / fpw;
-                int threads = 256;
-                threads = env_threads("VET_LUT_THREADS", threads);
-                bool il = false;
-                for (int k = 0; k < K; ++k) il = il || pl->lat[k].interleaved;
-                ProfScope ps(c, s, KID_SPATIAL);
-                // 2 rows in flight per lane group measured best (4 and 8 were tried, profiles/r01/v3_*)
-                const bool occ8 = K == 1 && threads == 256;
-                if (il && occ8) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2, true, true>), dim3(blocks), dim3(threads), lds, s, q);
-                else if (il) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2, true, false>), dim3(blocks), dim3(threads), lds, s, q);
-                else if (occ8) hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2, false, true>), dim3(blocks), dim3(threads), lds, s, q);
-                else hipLaunchKernelGGL((vet::k_spatial_lut<FROM_IDS, 2, false, false>), dim3(blocks), dim3(threads), lds, s, q);
-                HIP_TRY(hipGetLastError());
-                return VET_OK;
-            }
-        }
+        all_table = all_table && form[k] == F_TABLE;
+    }
+    // ---- weighted, table formulation: every lattice in one launch
+    if (all_table) {
+        int idx[vet::MAX_LATTICES];
+        for (int k = 0; k < K; ++k) idx[k] = k;
+        bool launched = false;
+        int rc = launch_lut<FROM_IDS>(pl, idx, K, src, U, T, nullptr, 0, 0, 0, d_entropy, d_assign, d_weights, d_present,
+                                      d_status, s, &launched);
+        if (launched) for (int k = 0; k < K; ++k) pl->lat[k].last_form = F_TABLE;
+        if (rc || launched) return rc;
+        for (int k = 0; k < K; ++k) form[k] = sweep_formulation(pl, pl->lat[k], U);   // histograms do not fit the LDS
     }
     if (K > 1) {
         int rc = ensure_ws(c, (size_t)K * T * sizeof(double));
@@ -393,8 +563,19 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
     }
     for (int k = 0; k < K; ++k) {
         const Lattice& L = pl->lat[k];
+        if (form[k] == F_TABLE) {
+            bool launched = false;
+            int rc = launch_lut<FROM_IDS>(pl, &k, 1, src, U, T, nullptr, 0, 0, 0, ent_k + (size_t)k * T,
+                                          k == 0 ? d_assign : nullptr, k == 0 ? d_weights : nullptr,
+                                          k == 0 ? d_present : nullptr, k == 0 ? d_status : nullptr, s, &launched);
+            if (rc) return rc;
+            if (launched) { pl->lat[k].last_form = F_TABLE; continue; }
+            form[k] = sweep_formulation(pl, L, U);
+        }
         // binned lattices (naive tiling) are always integer counts; the flag picks the normaliser
         const bool hist_weighted = pl->weighted != 0 && !L.binned;
+        const bool precise = hist_weighted && form[k] == F_PRECISE;
+        if (hist_weighted) pl->lat[k].last_form = form[k];
         Geometry g;
         int rc = spatial_geometry(c, L.n, U, hist_weighted, &g);
         if (rc) return rc;
@@ -409,7 +590,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         p.wc.max_ang = pl->max_ang;
         p.wc.inv_max = 1.0 / pl->max_ang;
         p.wc.power = pl->power;
-        p.wc.shift = ubits > 10 ? ubits - 10 : 0;   // per-tile sums of U weights stay below 2^62
+        p.wc.shift = sweep_shift(U);
         p.hmax = L.hmax;
         p.ent_k = ent_k + (size_t)k * T;
         p.assign = k == 0 ? d_assign : nullptr;
@@ -449,7 +630,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
             }
         }
         const int blocks = (T + g.FPW - 1) / g.FPW;
-        const void* fn = hist_weighted ? spatial_w_kernel<FROM_IDS>(weight_mode(pl), g.R)
+        const void* fn = hist_weighted ? spatial_w_kernel<FROM_IDS>(weight_mode(pl), g.R, precise)
                                        : (const void*)vet::k_spatial_u<FROM_IDS>;
         void* args[] = {(void*)&p};
         ProfScope ps(c, s, KID_SPATIAL);
@@ -702,7 +883,9 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
                 if (d->h_bin_lut[k][i] >= L.n)
                     return cleanup(fail(VET_ERR_INVALID, "lattice %d: bin %u of direction %lld >= %d bins", k,
                                         (unsigned)d->h_bin_lut[k][i], (long long)i, L.n));
-            PLAN_TRY(hipMalloc((void**)&L.d_nearest, (size_t)pl->n_dirs * sizeof(uint16_t)));
+            // one spare entry: k_spatial_u_lds copies the LUT in 32-bit words
+            PLAN_TRY(hipMalloc((void**)&L.d_nearest, ((size_t)pl->n_dirs + 1) * sizeof(uint16_t)));
+            PLAN_TRY(hipMemsetAsync(L.d_nearest + pl->n_dirs, 0, sizeof(uint16_t), s));
             PLAN_TRY(hipMemcpyAsync(L.d_nearest, d->h_bin_lut[k], (size_t)pl->n_dirs * sizeof(uint16_t),
                                     hipMemcpyHostToDevice, s));
             PLAN_TRY(hipStreamSynchronize(s));
@@ -716,7 +899,8 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
             unit[3 * t] = x / len; unit[3 * t + 1] = y / len; unit[3 * t + 2] = z / len;
         }
         PLAN_TRY(hipMalloc((void**)&L.d_tiles, unit.size() * sizeof(double)));
-        PLAN_TRY(hipMalloc((void**)&L.d_nearest, (size_t)pl->n_dirs * sizeof(uint16_t)));
+        PLAN_TRY(hipMalloc((void**)&L.d_nearest, ((size_t)pl->n_dirs + 1) * sizeof(uint16_t)));
+        PLAN_TRY(hipMemsetAsync(L.d_nearest + pl->n_dirs, 0, sizeof(uint16_t), s));
         PLAN_TRY(hipMemcpyAsync(L.d_tiles, unit.data(), unit.size() * sizeof(double), hipMemcpyHostToDevice, s));
         PLAN_TRY(hipStreamSynchronize(s));   // 'unit' goes out of scope
         const size_t lds = (size_t)L.n * 3 * sizeof(double);
@@ -732,19 +916,18 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
     }
     PLAN_TRY(hipStreamSynchronize(s));
     // the run kernels may need more than the default 64 KiB of dynamic LDS
-    for (int wm = 0; wm < 3; ++wm)
-        for (int R = 1; R <= 2; ++R) {
+    for (int R = 1; R <= 2; ++R) {
+        for (int wm = 0; wm < 3; ++wm) {
             PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<false>(wm, R), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
             PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<true>(wm, R), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
         }
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 2, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<false, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 2, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_lut<true, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+        PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<false>(0, R, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+        PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<true>(0, R, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    }
+    for (int v = 0; v < 8; ++v) {
+        PLAN_TRY(hipFuncSetAttribute(lut_kernel<false>(v & 1, v & 2, v & 4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+        PLAN_TRY(hipFuncSetAttribute(lut_kernel<true>(v & 1, v & 2, v & 4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    }
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
@@ -769,8 +952,10 @@ int vet_plan_destroy(vet_plan* pl) {
         if (L.d_nearest) (void)hipFree(L.d_nearest);
         if (L.d_tab_w) (void)hipFree(L.d_tab_w);
         if (L.d_tab_i) (void)hipFree(L.d_tab_i);
-        if (L.d_tab_len) (void)hipFree(L.d_tab_len);
+        if (L.d_tab_meta) (void)hipFree(L.d_tab_meta);
+        if (L.d_row_s) (void)hipFree(L.d_row_s);
     }
+    if (pl->d_alias) (void)hipFree(pl->d_alias);
     delete pl;
     return VET_OK;
 }
@@ -786,6 +971,23 @@ int vet_plan_set_table_policy(vet_plan* pl, int policy) {
 int vet_plan_table_stride(const vet_plan* pl, int k) {
     if (!pl || k < 0 || k >= (int)pl->lat.size()) return 0;
     return pl->lat[k].stride;
+}
+
+int vet_plan_last_formulation(const vet_plan* pl, int k) {
+    if (!pl || k < 0 || k >= (int)pl->lat.size()) return -1;
+    return pl->lat[k].last_form;
+}
+
+int vet_plan_error_bounds(vet_plan* pl, int k, double* table_bound, double* sweep_bound) {
+    if (!pl) return fail(VET_ERR_INVALID, "plan is NULL");
+    if (k < 0 || k >= (int)pl->lat.size()) return fail(VET_ERR_INVALID, "lattice index %d out of range", k);
+    if (pl->lat[k].binned) return fail(VET_ERR_INVALID, "lattice %d is binned (integer counts, exact)", k);
+    HIP_TRY(hipSetDevice(pl->ctx->device));
+    int rc = ensure_stats(pl, k, pl->ctx->stream);
+    if (rc) return rc;
+    if (table_bound) *table_bound = pl->lat[k].crit_tab;
+    if (sweep_bound) *sweep_bound = pl->lat[k].crit_base * std::ldexp(1.0, -52);
+    return VET_OK;
 }
 
 int vet_plan_read_dirs(vet_plan* pl, double* h_xyz) {
@@ -869,19 +1071,21 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
         total += (long)x.n_users * x.n_frames;
         total_frames += x.n_frames;
     }
-    bool table = pl->weighted && pl->table_policy >= 0 && !any_binned(pl) && K <= vet::MAX_LATTICES &&
-                 (pl->table_policy > 0 || pl->lat[0].stride > 0 || pl->samples_seen + total >= 16 * (long)pl->n_dirs);
-    if (table)
-        for (int k = 0; k < K && table; ++k) {
-            int rc = ensure_wtab(pl, k, s);
-            if (rc) return rc;
-            table = pl->lat[k].stride > 0;
-        }
+    int max_users = 0;
+    for (int v = 0; v < n_videos; ++v) max_users = videos[v].n_users > max_users ? videos[v].n_users : max_users;
+    bool table = table_requested(pl, total, max_users);
+    for (int k = 0; k < K && table; ++k) {
+        int form = F_SWEEP;
+        int rc = choose_formulation(pl, k, true, max_users, s, &form);
+        if (rc) return rc;
+        table = form == F_TABLE;
+    }
     int n_sum = 0;
     for (int k = 0; k < K; ++k) n_sum += pl->lat[k].n;
     std::vector<vet::VideoDesc>& desc = c->batch_desc;
     size_t lds_max = 0;
     if (table) {
+        const bool dedup = (uint64_t)pl->n_dirs <= vet::DEDUP_MAX_DIRS && !getenv("VET_NO_DEDUP");
         desc.resize(n_videos);
         int block = 0;
         for (int v = 0; v < n_videos && table; ++v) {
@@ -889,16 +1093,10 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
             vet::VideoDesc& d = desc[v];
             d.mu = x.d_mu; d.mv = x.d_mv; d.U = x.n_users; d.T = x.n_frames;
             d.entropy = x.d_entropy; d.assign = x.d_assign; d.present = x.d_present;
-            d.UC = d.U < 2048 ? d.U : 2048;
-            int fpw = lut_frames_per_wg(d.U, total_frames, c->n_cu, n_sum);
-            size_t lds = 0;
-            for (;; fpw /= 2) {
-                lds = (size_t)fpw * n_sum * 8 + (size_t)fpw * d.UC * 6 + (size_t)2 * fpw * 4 + 64;
-                if (lds <= c->lds_max || fpw == 1) break;
-            }
-            if (lds > c->lds_max) table = false;
-            d.FPW = fpw; d.block0 = block; d.pad_ = 0;
-            block += (d.T + fpw - 1) / fpw;
+            const size_t lds = batch_video_geometry(c, d.U, total_frames, n_sum, dedup, &d.FPW, &d.UC);
+            if (lds == 0) table = false;
+            d.block0 = block; d.pad_ = 0;
+            block += (d.T + d.FPW - 1) / d.FPW;
             lds_max = lds > lds_max ? lds : lds_max;
         }
         if (table) {
@@ -906,28 +1104,13 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
             int rc = pooled(c, 7, desc.size() * sizeof(vet::VideoDesc), &d_desc);
             if (rc) return rc;
             HIP_TRY(hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(vet::VideoDesc), hipMemcpyHostToDevice, s));
-            vet::LutParams q;
-            q.videos = (const vet::VideoDesc*)d_desc; q.n_videos = n_videos;
-            q.src = vet::SampleSrc{nullptr, nullptr, nullptr, pl->W, pl->H, (long)pl->n_dirs};
-            q.U = 0; q.T = 0;
-            q.nearest = pl->lat[0].d_nearest;
-            q.K = K; q.n_sum = n_sum;
-            for (int k = 0; k < K; ++k) {
-                const Lattice& L = pl->lat[k];
-                q.lat[k].tab_w = L.d_tab_w; q.lat[k].tab_i = L.d_tab_i; q.lat[k].tab_len = L.d_tab_len;
-                q.lat[k].stride = L.stride; q.lat[k].gs_log2 = L.gs_log2; q.lat[k].interleaved = L.interleaved ? 1 : 0;
-                q.lat[k].n = L.n; q.lat[k].hmax = L.hmax;
-            }
-            q.entropy = nullptr; q.assign = nullptr; q.weights = nullptr; q.present = nullptr; q.status = d_status;
-            q.FPW = 1; q.UC = 1;
-            pl->samples_seen += total;
-            ProfScope ps(c, s, KID_SPATIAL);
-            bool il = false;
-            for (int k = 0; k < K; ++k) il = il || pl->lat[k].interleaved;
-            if (il) hipLaunchKernelGGL((vet::k_spatial_lut<false, 2, true, true>), dim3((unsigned)block), dim3(256), lds_max, s, q);
-            else hipLaunchKernelGGL((vet::k_spatial_lut<false, 2, false, true>), dim3((unsigned)block), dim3(256), lds_max, s, q);
-            HIP_TRY(hipGetLastError());
-            return VET_OK;
+            int idx[vet::MAX_LATTICES];
+            for (int k = 0; k < K; ++k) idx[k] = k;
+            const vet::SampleSrc src{nullptr, nullptr, nullptr, pl->W, pl->H, (long)pl->n_dirs};
+            bool launched = false;
+            for (int k = 0; k < K; ++k) pl->lat[k].last_form = F_TABLE;
+            return launch_lut<false>(pl, idx, K, src, 0, 0, (const vet::VideoDesc*)d_desc, n_videos, block, lds_max, nullptr,
+                                     nullptr, nullptr, nullptr, d_status, s, &launched);
         }
     }
     for (int v = 0; v < n_videos; ++v) {

@@ -26,6 +26,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace vet {
 
@@ -223,13 +224,14 @@ __device__ __forceinline__ unsigned long long fov_weight_fx(double c, const Weig
 // Entropy of the workgroup's frames from their fixed-point tile histograms
 // (entropy_utils.py:194-211, weighted mode: normaliser log2(n)).  Wave w takes frames w, w+NW, ...
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void weighted_frame_entropy(const unsigned long long* hist, const int* cnt_frame, int nf,
-                                                       long f0, int n, double fx_scale, double hmax,
+template <typename HT>
+__device__ __forceinline__ void weighted_frame_entropy(const HT* hist, const int* cnt_frame, int nf,
+                                                       long f0, int n, double inv_unit, double hmax,
                                                        double* ent_k, double* weights, int32_t* present,
                                                        int32_t* status) {
     const int NW = blockDim.x >> 6, lane = lane_id(), wv = wave_id();
     for (int fl = wv; fl < nf; fl += NW) {
-        const unsigned long long* hrow = hist + (size_t)fl * n;
+        const HT* hrow = hist + (size_t)fl * n;
         // total weight: up to U*n/4 fixed-point units, which can exceed 64 bits, so it is summed
         // in FP64 (fixed lane order + butterfly => still a pure function of the histogram)
         double totd = 0.0;
@@ -237,12 +239,12 @@ __device__ __forceinline__ void weighted_frame_entropy(const unsigned long long*
         totd = wave_sum(totd);
         double h = 0.0;
         for (int t = lane; t < n; t += WAVE) {
-            const unsigned long long v = hrow[t];
-            if (v) {
+            const HT v = hrow[t];
+            if (v != (HT)0) {
                 const double q = (double)v / totd;
                 h -= q * log2(q);
             }
-            if (weights) __builtin_nontemporal_store((double)v / fx_scale, weights + (f0 + fl) * (long)n + t);
+            if (weights) __builtin_nontemporal_store((double)v * inv_unit, weights + (f0 + fl) * (long)n + t);
         }
         h = wave_sum(h);
         if (lane == 0) {
@@ -298,12 +300,26 @@ struct SpatialParams {
                                   // with use_weight_distribution, entropy_utils.py:442-447)
 };
 
-template <bool FROM_IDS, int WMODE, int R>
+// the reference's weight, evaluated as the reference does (entropy_utils.py:124-137): 0 when not d < max
+__device__ __forceinline__ double fov_weight_exact(double c, const WeightCfg& w) {
+    c = fmin(fmax(c, -1.0), 1.0);
+    const double d = acos(c);
+    if (!(d < w.max_ang)) return 0.0;
+    return pow((w.max_ang - d) / w.max_ang, w.power);
+}
+
+// PRECISE: the histogram is FP64 (ds_add_f64) and the weights are the exact ocml values, for plans whose
+// entropies can be so small that no fixed-point resolution keeps them within 1e-6 relative (k_row_stats).
+// Every tile is owned by one wave, users are staged in column order (absent users as NaN directions, no
+// compaction) and a wave's LDS atomics execute in program order, so the per-tile sums run in the
+// reference's own order (users in column order) and the result is reproducible run to run.
+template <bool FROM_IDS, int WMODE, int R, bool PRECISE>
 __global__ void k_spatial_w(const SpatialParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using HT = typename std::conditional<PRECISE, double, unsigned long long>::type;
     constexpr int QC = WAVE * (R + 1);                                          // queue capacity
     const int NW = blockDim.x >> 6;
-    unsigned long long* hist = (unsigned long long*)smem;                        // [FPW][n]
+    HT* hist = (HT*)smem;                                                        // [FPW][n]
     double* dirs = (double*)(hist + (size_t)p.FPW * p.n);                       // [FPW][UC][3]
     double* qc = dirs + (size_t)p.FPW * p.UC * 3;                                // [NW][QC]
     uint16_t* qt = (uint16_t*)(qc + (size_t)NW * QC);                            // [NW][QC]
@@ -314,7 +330,7 @@ __global__ void k_spatial_w(const SpatialParams p) {
     const long f0 = (long)blockIdx.x * p.FPW;
     const int nf = (int)min((long)p.FPW, (long)p.T - f0);
 
-    for (int i = tid; i < p.FPW * p.n; i += blockDim.x) hist[i] = 0ull;
+    for (int i = tid; i < p.FPW * p.n; i += blockDim.x) hist[i] = (HT)0;
     for (int i = tid; i < 2 * p.FPW; i += blockDim.x) cnt_chunk[i] = 0;
     bool bad = false;
     double* my_qc = qc + wv * QC;
@@ -330,7 +346,14 @@ __global__ void k_spatial_w(const SpatialParams p) {
             const int fl = i / uc, uu = i - fl * uc;
             const long idx = (f0 + fl) * (long)p.U + u0 + uu;
             const int id = sample_dir<FROM_IDS>(p.src, idx, bad);
-            if (id >= 0) {
+            if (PRECISE) {
+                double* dst = dirs + ((size_t)fl * p.UC + uu) * 3;
+                const double nan = __builtin_nan("");
+                dst[0] = id >= 0 ? p.dir_unit[3 * (long)id] : nan;
+                dst[1] = id >= 0 ? p.dir_unit[3 * (long)id + 1] : nan;
+                dst[2] = id >= 0 ? p.dir_unit[3 * (long)id + 2] : nan;
+                if (id >= 0) atomicAdd(&cnt_chunk[fl], 1);
+            } else if (id >= 0) {
                 const int slot = atomicAdd(&cnt_chunk[fl], 1);
                 double* dst = dirs + ((size_t)fl * p.UC + slot) * 3;
                 dst[0] = p.dir_unit[3 * (long)id];
@@ -354,16 +377,16 @@ __global__ void k_spatial_w(const SpatialParams p) {
                 const int ts = valid[r] ? tt[r] : 0;
                 tx[r] = p.tiles[3 * ts]; ty[r] = p.tiles[3 * ts + 1]; tz[r] = p.tiles[3 * ts + 2];
             }
-            const int nu = __builtin_amdgcn_readfirstlane(cnt_chunk[fl]);
+            const int nu = PRECISE ? uc : __builtin_amdgcn_readfirstlane(cnt_chunk[fl]);
             const double* dl = dirs + (size_t)fl * p.UC * 3;
-            unsigned long long* hrow = hist + (size_t)fl * p.n;
+            HT* hrow = hist + (size_t)fl * p.n;
             int qn = 0;
             for (int j = 0; j < nu; ++j) {
                 const double dx = dl[3 * j], dy = dl[3 * j + 1], dz = dl[3 * j + 2];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const double c = fma(dz, tz[r], fma(dy, ty[r], dx * tx[r]));
-                    const bool hit = valid[r] && (c > p.cos_cull);
+                    const bool hit = valid[r] && (c > p.cos_cull);        // NaN direction (absent): never
                     const unsigned long long mask = __ballot(hit);
                     if (hit) {
                         const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
@@ -376,25 +399,35 @@ __global__ void k_spatial_w(const SpatialParams p) {
                 while (qn >= WAVE) {
                     qn -= WAVE;
                     __builtin_amdgcn_wave_barrier();
-                    const unsigned long long fx = fov_weight_fx<WMODE>(my_qc[qn + lane], p.wc);
                     const int t = my_qt[qn + lane];
-                    if (fx) atomicAdd(&hrow[t], fx);
+                    if (PRECISE) {
+                        const double w = fov_weight_exact(my_qc[qn + lane], p.wc);
+                        if (w > 0.0) atomicAdd((double*)&hrow[t], w);
+                    } else {
+                        const unsigned long long fx = fov_weight_fx<WMODE>(my_qc[qn + lane], p.wc);
+                        if (fx) atomicAdd((unsigned long long*)&hrow[t], fx);
+                    }
                     __builtin_amdgcn_wave_barrier();
                 }
             }
             __builtin_amdgcn_wave_barrier();
             if (lane < qn) {
-                const unsigned long long fx = fov_weight_fx<WMODE>(my_qc[lane], p.wc);
                 const int t = my_qt[lane];
-                if (fx) atomicAdd(&hrow[t], fx);
+                if (PRECISE) {
+                    const double w = fov_weight_exact(my_qc[lane], p.wc);
+                    if (w > 0.0) atomicAdd((double*)&hrow[t], w);
+                } else {
+                    const unsigned long long fx = fov_weight_fx<WMODE>(my_qc[lane], p.wc);
+                    if (fx) atomicAdd((unsigned long long*)&hrow[t], fx);
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
 
-    weighted_frame_entropy(hist, cnt_frame, nf, f0, p.n, (double)(1ull << (52 - p.wc.shift)), p.hmax, p.ent_k,
-                           p.weights, p.present, p.status);
+    weighted_frame_entropy<HT>(hist, cnt_frame, nf, f0, p.n, PRECISE ? 1.0 : 1.0 / (double)(1ull << (52 - p.wc.shift)),
+                               p.hmax, p.ent_k, p.weights, p.present, p.status);
     if (p.status) {
         const unsigned long long anybad = __ballot(bad);
         if (anybad && lane == 0) atomicAdd(&p.status[0], (int)__popcll(anybad));
@@ -406,12 +439,86 @@ __global__ void k_spatial_w(const SpatialParams p) {
 // and the weight of a (direction, tile) pair depends on nothing else, so for videos with more
 // samples than directions the rows  {(tile, w)} : w > 0  are evaluated once per plan (exact
 // ocml acos / pow, any fov and power) and the per-frame histogram becomes a gather of rows:
-//   hist[t] += w(dir(u), t)   for the ~n/4 tiles in the user's FoV.
-// Row d lives at w[d*stride .. ] (u32 fixed point, w * 2^32 rounded, saturating) and
-// idx[d*stride ..] (u16 tile), sorted by tile, zero padded.
+//   hist[t] += count(d) * w(d, t)   for the distinct directions d of the frame's users and the ~n/4
+//   tiles in d's FoV.
+// Row d lives at w[d*stride .. ] (u32 mantissas) and idx[d*stride ..] (u16 tile), sorted by tile,
+// zero padded.  Block floating point per ROW: with e = ceil(log2(largest weight of the row)) clamped
+// to [-TAB_X, 0], entry = rint(w * 2^(32 - e)) (saturating), and the gather adds
+// entry * (count << (TAB_X + e)) to a 64-bit histogram in units of 2^-(32 + TAB_X): a row whose
+// weights are all small (narrow FoV, large power) keeps 32 significant bits below its own maximum
+// instead of below 1.0.  meta[d] = entries in use | (TAB_X + e) << 16.
+//
+// k_row_stats (once per lattice, before the first weighted run) evaluates every row exactly and
+// decides whether integer histograms are inside the 1e-6 relative contract for EVERY possible frame:
+// with absolute step q_d on the entries of row d, k_d entries, exact row sum S_d and row entropy H_d,
+//   |dH| <= 36.5 * sum_i c_i k_i q_i / S   and   H >= sum_i c_i S_i H_i / S   (entropy is concave)
+// for a frame made of rows i with multiplicities c_i, hence  |dH| / H <= max_d 36.5 q_d k_d / (S_d H_d).
+// Plans where that bound exceeds 1e-7 (rows with a single tile in the FoV, weights spanning many
+// orders of magnitude) take the FP64 formulation (k_spatial_w<PRECISE>) instead.
 // k_wtab<false> finds the longest row (conservative cone test), k_wtab<true> fills the rows.
 // One wave per direction; lane = tile.
 // ------------------------------------------------------------------------------------------
+constexpr int TAB_X = 16;       // histogram unit 2^-(32+TAB_X): sums of < 2^16 weights <= 1 fit 64 bits
+
+struct StatsParams {
+    const double* dir_unit;
+    long D;
+    const double* tiles;
+    int n;
+    double cos_cull;
+    WeightCfg wc;
+    uint8_t* row_s;             // [D+1] TAB_X + e per row (row D = the all-zero row)
+    unsigned long long* crit;   // [2] bit patterns of non-negative doubles (atomicMax):
+                                //   [0] max_d 36.5 q_d k_d / (S_d H_d)   with the table's q_d = 2^(e_d - 33)
+                                //   [1] max_d 36.5 k_d / (S_d H_d)       (times the sweep's step, 2^(shift-53))
+};
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+__global__ void k_row_stats(const StatsParams p) {
+    const int lane = lane_id();
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    double worst_tab = 0.0, worst_sweep = 0.0;
+    for (long d = wave; d < p.D; d += nwaves) {
+        const double dx = p.dir_unit[3 * d], dy = p.dir_unit[3 * d + 1], dz = p.dir_unit[3 * d + 2];
+        double S = 0.0, L = 0.0, mx = 0.0;
+        int k = 0;
+        for (int t0 = 0; t0 < p.n; t0 += WAVE) {
+            const int t = t0 + lane;
+            const bool valid = t < p.n;
+            const int ts = valid ? t : 0;
+            const double c = fma(dz, p.tiles[3 * ts + 2], fma(dy, p.tiles[3 * ts + 1], dx * p.tiles[3 * ts]));
+            if (valid && c > p.cos_cull) {
+                const double wt = fov_weight_exact(c, p.wc);
+                if (wt > 0.0) { ++k; S += wt; L += wt * log2(wt); mx = fmax(mx, wt); }
+            }
+        }
+        k = wave_sum(k); S = wave_sum(S); L = wave_sum(L); mx = wave_max(mx);
+        int e = 0;
+        if (mx > 0.0) (void)frexp(mx, &e);                  // mx <= 2^e
+        e = min(0, max(-TAB_X, e));
+        if (lane == 0) p.row_s[d] = (uint8_t)(TAB_X + e);
+        if (k >= 1) {
+            // row entropy -sum (w/S) log2(w/S) = log2 S - (sum w log2 w) / S; its own rounding error (~1e-15)
+            // only matters where the bound is hopeless anyway
+            const double H = k >= 2 ? fmax(log2(S) - L / S, 0.0) : 0.0;
+            const double base = H > 0.0 ? 36.5 * (double)k / (S * H) : __builtin_inf();
+            worst_tab = fmax(worst_tab, base * ldexp(1.0, e - 33));
+            worst_sweep = fmax(worst_sweep, base);
+        }
+    }
+    if (lane == 0) {
+        if (p.row_s && wave == 0) p.row_s[p.D] = (uint8_t)TAB_X;
+        if (worst_tab > 0.0) atomicMax(&p.crit[0], (unsigned long long)__double_as_longlong(worst_tab));
+        if (worst_sweep > 0.0) atomicMax(&p.crit[1], (unsigned long long)__double_as_longlong(worst_sweep));
+    }
+}
+
 struct WtabParams {
     const double* dir_unit;
     long D;
@@ -422,7 +529,8 @@ struct WtabParams {
     int stride;
     uint32_t* w;
     uint16_t* idx;
-    uint16_t* len;      // [D] entries in use per row
+    uint32_t* meta;     // [D+1] entries in use per row | row shift << 16
+    const uint8_t* row_s;
     int* maxcount;
     int gs_log2;        // >= 0: well-filled blocks dealt over the 2^gs_log2 lanes of a gather group
 };
@@ -459,6 +567,8 @@ __global__ void k_wtab(const WtabParams p) {
     for (long d = wave; d < p.D; d += nwaves) {
         const double dx = p.dir_unit[3 * d], dy = p.dir_unit[3 * d + 1], dz = p.dir_unit[3 * d + 2];
         int count = 0;
+        const int row_shift = FILL ? (int)p.row_s[d] : 0;
+        const double scale = ldexp(1.0, 32 + TAB_X - row_shift);        // 2^(32 - e)
         for (int t0 = 0; t0 < p.n; t0 += WAVE) {
             const int t = t0 + lane;
             const bool valid = t < p.n;
@@ -467,13 +577,7 @@ __global__ void k_wtab(const WtabParams p) {
             bool hit = valid && (c > p.cos_cull);
             unsigned w32 = 0u;
             if (FILL) {
-                if (hit) {
-                    const double cc = fmin(fmax(c, -1.0), 1.0);
-                    const double ang = acos(cc);
-                    double wt = 0.0;
-                    if (ang < p.wc.max_ang) wt = pow((p.wc.max_ang - ang) / p.wc.max_ang, p.wc.power);
-                    w32 = (unsigned)fmin(rint(wt * 4294967296.0), 4294967295.0);
-                }
+                if (hit) w32 = (unsigned)fmin(rint(fov_weight_exact(c, p.wc) * scale), 4294967295.0);
                 hit = w32 != 0u;
             }
             const unsigned long long mask = __ballot(hit);
@@ -492,7 +596,7 @@ __global__ void k_wtab(const WtabParams p) {
                 p.w[d * p.stride + pos] = 0u;
                 p.idx[d * p.stride + pos] = (uint16_t)(pos % p.n);
             }
-            if (lane == 0) p.len[d] = (uint16_t)count;
+            if (lane == 0) p.meta[d] = (uint32_t)count | ((uint32_t)row_shift << 16);
             // well-filled blocks of 16-lane rows: deal the entries by class (one wave pass per block, lane =
             // sorted entry; the loads of all lanes have returned before the first store issues)
             if (p.gs_log2 == 4) {
@@ -554,24 +658,26 @@ __global__ void k_wtab(const WtabParams p) {
             // lane l of a 16-lane group adds its zeros to tile l: 16 classes, no conflict
             p.idx[p.D * p.stride + pos] = (uint16_t)(p.gs_log2 == 4 ? (pos >> 2) & 15 : pos % p.n);
         }
-        if (lane == 0) p.len[p.D] = 0;
+        if (lane == 0) p.meta[p.D] = (uint32_t)TAB_X << 16;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// Row walk shared by the table kernels: the workgroup adds the ELL rows of the directions
-// fids[0..nu) into the LDS histogram hrow.  A group of GS = 2^gs_log2 lanes walks one row
-// (coalesced u32 + u16 loads); UN rows per group are in flight; rows are zero padded, so a
-// group walks to the longest of its UN rows only.
+// Row walk shared by the table kernels: the workgroup adds the ELL rows of the frame's distinct
+// directions into the LDS histogram hrow.  frows[j] = row << 12 | multiplicity (DEDUP) or the row
+// (multiplicity 1); fmeta[j] = the row's meta word.  A group of GS = 2^gs_log2 lanes walks one
+// row; UN rows per group are in flight; rows are zero padded, so a group walks to the longest of
+// its UN rows only.
 // ------------------------------------------------------------------------------------------
-template <int UN, bool INTERLEAVED>
-__device__ __forceinline__ void walk_rows(const int* fids, const uint16_t* flens, int nu, unsigned long long* hrow,
+template <int UN, bool INTERLEAVED, bool DEDUP>
+__device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t* fmeta, int nu,
+                                          unsigned long long* hrow,
                                           const uint32_t* __restrict__ tab_w, const uint16_t* __restrict__ tab_i,
                                           int stride, int gs_log2, long zero_row) {
     // Every lane takes one 4-slot chunk per block: one 16-byte load of weights, one 8-byte load of
     // tiles (stride is a multiple of the block, so chunks are 16 / 8 byte aligned), then four
-    // unconditional ds_add_u64: padding slots and idle lanes (which walk the all-zero row) add 0
-    // to distinct tiles — no predicates around the adds.
+    // unconditional ds_add_u64 of entry * (multiplicity << row shift): padding slots and idle lanes
+    // (which walk the all-zero row) add 0 to distinct tiles — no predicates around the adds.
     const int NW = blockDim.x >> 6, lane = lane_id(), wv = wave_id();
     const int GS = 1 << gs_log2, UPW = WAVE >> gs_log2;
     const int sub = lane >> gs_log2, sl = lane & (GS - 1);
@@ -579,13 +685,16 @@ __device__ __forceinline__ void walk_rows(const int* fids, const uint16_t* flens
     for (int j0 = wv * UPW; j0 < nu; j0 += UN * step) {
         long row[UN];
         int len[UN];
+        uint32_t mult[UN];
         int longest = 0;
 #pragma unroll
         for (int k = 0; k < UN; ++k) {
             const int j = j0 + k * step + sub;
             const bool on = j < nu;
-            row[k] = on ? (long)fids[j] * stride : zero_row;
-            len[k] = on ? (int)flens[j] : 0;
+            const uint32_t pk = on ? frows[j] : 0u, m = on ? fmeta[j] : 0u;
+            row[k] = on ? (long)(DEDUP ? pk >> 12 : pk) * stride : zero_row;
+            len[k] = (int)(m & 0xFFFFu);
+            mult[k] = (DEDUP ? pk & 0xFFFu : (on ? 1u : 0u)) << (m >> 16);
             longest = max(longest, len[k]);
         }
         // block base eb counts sorted entries; the lane's chunk sits at slots eb + 4*sl .. +3 and holds
@@ -619,10 +728,10 @@ __device__ __forceinline__ void walk_rows(const int* fids, const uint16_t* flens
             }
 #pragma unroll
             for (int k = 0; k < UN; ++k) {
-                atomicAdd(&hrow[t[k].x], (unsigned long long)w[k].x);
-                atomicAdd(&hrow[t[k].y], (unsigned long long)w[k].y);
-                atomicAdd(&hrow[t[k].z], (unsigned long long)w[k].z);
-                atomicAdd(&hrow[t[k].w], (unsigned long long)w[k].w);
+                atomicAdd(&hrow[t[k].x], (unsigned long long)w[k].x * mult[k]);
+                atomicAdd(&hrow[t[k].y], (unsigned long long)w[k].y * mult[k]);
+                atomicAdd(&hrow[t[k].z], (unsigned long long)w[k].z * mult[k]);
+                atomicAdd(&hrow[t[k].w], (unsigned long long)w[k].w * mult[k]);
             }
         }
     }
@@ -631,20 +740,28 @@ __device__ __forceinline__ void walk_rows(const int* fids, const uint16_t* flens
 // ------------------------------------------------------------------------------------------
 // k_spatial_lut — compute_spatial_entropy (entropy_utils.py:147-211), FoV-weighted mode, through
 // the direction weight table.  FPW frames per workgroup.
-// LDS:  hist u64 [FPW][n]   per-frame tile weight sums (units of 2^-32)
-//       ids  i32 [FPW][UC]  direction ids of the present users (compacted)
-//       lens u16 [FPW][UC]  their row lengths in the lattice being gathered
-//       cnt  i32 [FPW] chunk-present, [FPW] frame-present
-// A group of GS = 2^gs_log2 lanes walks one user's row (coalesced u32 + u16 loads) and adds the
-// non-zero entries into the frame histogram with ds_add_u64; a wave serves 64/GS users at once
-// and two such steps are issued back to back to keep more loads in flight.
+// LDS:  hist u64 [FPW][n_sum]  per-frame tile weight sums, units of 2^-(32+TAB_X)
+//       hash u32 [FPW][HS]     DEDUP: open-addressing set of the frame's rows, slot = row << 12 | count;
+//                              shares the histogram's space (the set is compacted before the first add)
+//                              unless the users arrive in several chunks
+//       rows u32 [FPW][UC]     the frame's distinct rows (slot words), or one row per present user
+//       meta u32 [FPW][UC]     their meta words in the lattice being gathered
+//       cnt  i32 [FPW] rows in the chunk, [FPW] users present in the frame
+// Prologue: sample -> direction id -> canonical row (alias: directions with the same Vector — the pole
+// row, the -180 / -90 remaps — share one row) -> set insert.  Users looking in exactly the same
+// direction cost one row walk with a multiplicity instead of one each: 1024 users are ~710 distinct
+// rows on the random-walk workload, ~180 on a clustered audience.
+// A group of GS = 2^gs_log2 lanes walks one row (16-byte weight + 8-byte tile loads) and adds
+// entry * multiplicity into the frame histogram with ds_add_u64; a wave serves 64/GS rows at once and
+// two such steps are issued back to back to keep more loads in flight.
 // ------------------------------------------------------------------------------------------
 constexpr int MAX_LATTICES = 8;
+constexpr unsigned DEDUP_MAX_DIRS = (1u << 20) - 1;      // row ids must fit 20 bits of a slot word
 
 struct LutLattice {
     const uint32_t* tab_w;
     const uint16_t* tab_i;
-    const uint16_t* tab_len;
+    const uint32_t* tab_meta;
     int stride, gs_log2, n, interleaved;
     double hmax;
 };
@@ -667,6 +784,7 @@ struct LutParams {
     SampleSrc src;
     int U, T;
     const uint16_t* nearest;      // lattice 0 (assign)
+    const uint32_t* alias;        // [n_dirs] direction id -> canonical row
     int K;                        // lattices handled by this launch (<= MAX_LATTICES)
     int n_sum;                    // sum of n over the K lattices
     LutLattice lat[MAX_LATTICES];
@@ -678,14 +796,28 @@ struct LutParams {
     int FPW, UC;
 };
 
-// All K lattices of the plan in one launch: the samples are read once, every user's K rows are
-// gathered into K histograms, and avg_entropy = (e_0 + ... + e_{K-1}) / K is formed in lattice
-// order as the reference does (spatial_entropy.py:142-156) — no per-lattice pass, no finalize.
+// hash slots per frame: power of two >= 2 * UC, at least one wave's worth
+__host__ __device__ __forceinline__ int lut_hash_slots(int UC) {
+    int hs = 64;
+    while (hs < 2 * UC) hs <<= 1;
+    return hs;
+}
+// LDS bytes of a workgroup; the kernel and the host must agree
+__host__ __device__ __forceinline__ size_t lut_lds_bytes(int U, int UC, int FPW, int n_sum, bool dedup) {
+    const size_t hist = (size_t)FPW * n_sum * 8, hash = dedup ? (size_t)FPW * lut_hash_slots(UC) * 4 : 0;
+    const size_t a = (dedup && U <= UC) ? (hist > hash ? hist : hash) : hist + hash;
+    return ((a + 15) & ~(size_t)15) + (size_t)FPW * UC * 8 + (size_t)2 * FPW * 4 + 64;
+}
+
+// All K lattices of the plan in one launch: the samples are read once, every row is gathered into K
+// histograms, and avg_entropy = (e_0 + ... + e_{K-1}) / K is formed in lattice order as the
+// reference does (spatial_entropy.py:142-156) — no per-lattice pass, no finalize.
 // IL: some lattice of the plan has interleaved rows (otherwise only the plain walk is compiled in).
 // OCC8: compiled for 8 workgroups of 256 threads per CU (64 VGPRs) instead of 7 (68-70 VGPRs): measured
 // 2 % (random walk) to 6.5 % (clustered) faster on single-lattice plans and 7 % on batches of short
 // videos, but 2-4 % slower on one multi-lattice video (profiles/r01/v6_table_occupancy.log).
-template <bool FROM_IDS, int UN, bool IL, bool OCC8>
+// DEDUP: per-frame set of distinct rows with multiplicities (direction tables of < 2^20 rows).
+template <bool FROM_IDS, int UN, bool IL, bool OCC8, bool DEDUP>
 __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // the video this workgroup works on: the launch's only one, or one of a batch
@@ -708,57 +840,105 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
         entropy = d.entropy; assign = d.assign; present = d.present; weights = nullptr;
         blk -= d.block0;
     }
+    const int HS = DEDUP ? lut_hash_slots(UC) : 0;
+    const bool overlay = DEDUP && U <= UC;                                       // one chunk: set and histogram share space
+    const size_t hist_bytes = (size_t)FPW * p.n_sum * 8, hash_bytes = (size_t)FPW * HS * 4;
+    const size_t a_bytes = overlay ? (hist_bytes > hash_bytes ? hist_bytes : hash_bytes) : hist_bytes + hash_bytes;
     unsigned long long* hist = (unsigned long long*)smem;                        // [FPW][n_sum]
-    int* ids = (int*)(hist + (size_t)FPW * p.n_sum);                             // [FPW][UC]
-    int* cnt_chunk = ids + (size_t)FPW * UC;                                     // [FPW]
+    uint32_t* hash = (uint32_t*)(smem + (overlay ? 0 : hist_bytes));             // [FPW][HS]
+    uint32_t* rows = (uint32_t*)(smem + ((a_bytes + 15) & ~(size_t)15));         // [FPW][UC]
+    uint32_t* meta = rows + (size_t)FPW * UC;                                    // [FPW][UC]
+    int* cnt_chunk = (int*)(meta + (size_t)FPW * UC);                            // [FPW]
     int* cnt_frame = cnt_chunk + FPW;                                            // [FPW]
-    uint16_t* lens = (uint16_t*)(cnt_frame + FPW);                               // [FPW][UC] row lengths
     const int NW = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const long f0 = blk * FPW;
     const int nf = (int)min((long)FPW, (long)T - f0);
-    for (int i = tid; i < FPW * p.n_sum; i += blockDim.x) hist[i] = 0ull;
+    if (!overlay)
+        for (int i = tid; i < FPW * p.n_sum; i += blockDim.x) hist[i] = 0ull;
     for (int i = tid; i < 2 * FPW; i += blockDim.x) cnt_chunk[i] = 0;
     bool bad = false;
+    const int hs_shift = 32 - (31 - __clz(HS | 1));
     for (int u0 = 0; u0 < U; u0 += UC) {
         const int uc = min(UC, U - u0);
         __syncthreads();
         for (int i = tid; i < FPW; i += blockDim.x) cnt_chunk[i] = 0;
+        if (DEDUP)
+            for (int i = tid; i < FPW * HS; i += blockDim.x) hash[i] = EMPTY_KEY;
         __syncthreads();
         for (int i = tid; i < nf * uc; i += blockDim.x) {
             const int fl = i / uc, uu = i - fl * uc;
             const long idx = (f0 + fl) * (long)U + u0 + uu;
             const int id = sample_dir<FROM_IDS>(src, idx, bad);
-            if (id >= 0) ids[(size_t)fl * UC + atomicAdd(&cnt_chunk[fl], 1)] = id;
             if (assign) __builtin_nontemporal_store(id >= 0 ? (int)p.nearest[id] : -1, assign + idx);
+            if (id < 0) continue;
+            const uint32_t row = p.alias[id];
+            if (DEDUP) {
+                uint32_t* tab = hash + (size_t)fl * HS;
+                unsigned h = (row * 2654435761u) >> hs_shift;
+                for (;;) {
+                    unsigned cur = tab[h];
+                    if (cur == EMPTY_KEY) {
+                        cur = atomicCAS(&tab[h], EMPTY_KEY, (row << 12) | 1u);
+                        if (cur == EMPTY_KEY) break;
+                    }
+                    if ((cur >> 12) == row) { atomicAdd(&tab[h], 1u); break; }
+                    h = (h + 1) & (unsigned)(HS - 1);
+                }
+            } else {
+                rows[(size_t)fl * UC + atomicAdd(&cnt_chunk[fl], 1)] = row;
+            }
         }
         __syncthreads();
-        for (int i = tid; i < FPW; i += blockDim.x) cnt_frame[i] += cnt_chunk[i];
+        if (DEDUP) {
+            // compact the sets into row lists; a wave's 64 slots belong to one frame (HS is a multiple of 64)
+            for (int s0 = wv * WAVE; s0 < FPW * HS; s0 += NW * WAVE) {
+                const int fl = s0 / HS;
+                const uint32_t v = hash[s0 + lane];
+                const bool on = v != EMPTY_KEY;
+                const unsigned long long m = __ballot(on);
+                if (m == 0ull) continue;
+                const int users = wave_sum(on ? (int)(v & 0xFFFu) : 0);
+                int base = 0;
+                if (lane == 0) {
+                    base = atomicAdd(&cnt_chunk[fl], (int)__popcll(m));
+                    atomicAdd(&cnt_frame[fl], users);
+                }
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (on) rows[(size_t)fl * UC + base + below(m)] = v;
+            }
+            __syncthreads();
+            if (overlay)
+                for (int i = tid; i < FPW * p.n_sum; i += blockDim.x) hist[i] = 0ull;
+        } else {
+            for (int i = tid; i < FPW; i += blockDim.x) cnt_frame[i] += cnt_chunk[i];
+        }
         int hoff = 0;
         for (int k = 0; k < p.K; ++k) {
             const LutLattice& L = p.lat[k];
-            // row lengths of this lattice for every staged user: one parallel gather, so the walk
-            // below has no dependent global load in front of its row loads
+            // meta words (length, shift) of this lattice for every staged row: one parallel gather, so the
+            // walk below has no dependent global load in front of its row loads
             if (k) __syncthreads();
             for (int i = tid; i < nf * UC; i += blockDim.x) {
                 const int fl = i / UC, j = i - fl * UC;
-                if (j < cnt_chunk[fl]) lens[i] = L.tab_len[ids[i]];
+                if (j < cnt_chunk[fl]) meta[i] = L.tab_meta[DEDUP ? rows[i] >> 12 : rows[i]];
             }
             __syncthreads();
             for (int fl = 0; fl < nf; ++fl)
                 if (IL && L.interleaved)
-                    walk_rows<UN, true>(ids + (size_t)fl * UC, lens + (size_t)fl * UC, cnt_chunk[fl],
-                                        hist + (size_t)fl * p.n_sum + hoff, L.tab_w, L.tab_i, L.stride, L.gs_log2,
-                                        (long)src.n_dirs * L.stride);
+                    walk_rows<UN, true, DEDUP>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
+                                               hist + (size_t)fl * p.n_sum + hoff, L.tab_w, L.tab_i, L.stride, L.gs_log2,
+                                               (long)src.n_dirs * L.stride);
                 else
-                    walk_rows<UN, false>(ids + (size_t)fl * UC, lens + (size_t)fl * UC, cnt_chunk[fl],
-                                         hist + (size_t)fl * p.n_sum + hoff, L.tab_w, L.tab_i, L.stride, L.gs_log2,
-                                         (long)src.n_dirs * L.stride);
+                    walk_rows<UN, false, DEDUP>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
+                                                hist + (size_t)fl * p.n_sum + hoff, L.tab_w, L.tab_i, L.stride, L.gs_log2,
+                                                (long)src.n_dirs * L.stride);
             hoff += L.n;
         }
     }
     __syncthreads();
     // entropy (entropy_utils.py:194-211, weighted: normaliser log2 n); wave w takes frames w, w+NW, ...
+    const double inv_unit = 1.0 / (4294967296.0 * (double)(1u << TAB_X));
     for (int fl = wv; fl < nf; fl += NW) {
         const unsigned long long* hrow = hist + (size_t)fl * p.n_sum;
         double total_entropy = 0.0;
@@ -775,7 +955,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
                     const double q = (double)v / totd;
                     h -= q * log2(q);
                 }
-                if (k == 0 && weights) __builtin_nontemporal_store((double)v / 4294967296.0, weights + (f0 + fl) * (long)n + t);
+                if (k == 0 && weights) __builtin_nontemporal_store((double)v * inv_unit, weights + (f0 + fl) * (long)n + t);
             }
             h = wave_sum(h);
             total_entropy += h / p.lat[k].hmax;

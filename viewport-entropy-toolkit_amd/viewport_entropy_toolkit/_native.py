@@ -88,6 +88,8 @@ SIGNATURES = {
     "vet_plan_n_dirs": (_I64, [_P]),
     "vet_plan_set_table_policy": (_I, [_P, _I]),
     "vet_plan_table_stride": (_I, [_P, _I]),
+    "vet_plan_last_formulation": (_I, [_P, _I]),
+    "vet_plan_error_bounds": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_D)]),
     "vet_plan_read_dirs": (_I, [_P, _P]),
     "vet_plan_read_nearest": (_I, [_P, _I, _P]),
     "vet_spatial_entropy": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -163,6 +165,17 @@ def _check(lib, rc: int):
 
 def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+VET_STREAM_LEGACY = 1
+
+
+def _stream(handle):
+    """hipStream_t handle -> the C-ABI's ``stream`` argument: ``None`` = the engine's own stream;
+    0 (torch's default stream) = the legacy null stream; anything else is the stream itself."""
+    if handle is None:
+        return None
+    return C.c_void_p(VET_STREAM_LEGACY if int(handle) == 0 else int(handle))
 
 
 class Engine:
@@ -286,6 +299,16 @@ class Plan:
     def table_stride(self, lattice: int = 0) -> int:
         return int(self.lib.vet_plan_table_stride(self.handle, lattice))
 
+    def last_formulation(self, lattice: int = 0) -> str:
+        """'table' | 'sweep' | 'precise' of the last weighted call ('' before any)."""
+        return {0: "table", 1: "sweep", 2: "precise"}.get(int(self.lib.vet_plan_last_formulation(self.handle, lattice)), "")
+
+    def error_bounds(self, lattice: int = 0):
+        """(table bound, sweep bound): proven worst-case relative entropy error of the integer formulations."""
+        a, b = C.c_double(), C.c_double()
+        _check(self.lib, self.lib.vet_plan_error_bounds(self.handle, lattice, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     # --- parity hooks ---------------------------------------------------------
     def read_dirs(self) -> np.ndarray:
         out = np.empty((self.n_dirs, 3), dtype=np.float64)
@@ -360,20 +383,21 @@ class Plan:
             ro += t
         return out
 
-    def spatial_batch_device(self, videos, d_status: int = 0, stream: int = 0):
-        """``videos``: ctypes array of ``Video`` (device pointers); asynchronous on ``stream``."""
+    def spatial_batch_device(self, videos, d_status: int = 0, stream=None):
+        """``videos``: ctypes array of ``Video`` (device pointers); asynchronous on ``stream``
+        (``None`` = the engine's own stream, 0 = the legacy null stream, else a hipStream_t handle)."""
         _check(self.lib, self.lib.vet_spatial_entropy_batch(self.handle, len(videos), videos, d_status or None,
-                                                            stream or None))
+                                                            _stream(stream)))
 
     # --- device-pointer runs (inputs resident in HBM; asynchronous on ``stream``) ----
     def spatial_device(self, d_mu: int, d_mv: int, n_users: int, n_frames: int, d_entropy: int, d_assign: int = 0,
-                       d_weights: int = 0, d_present: int = 0, d_status: int = 0, stream: int = 0):
+                       d_weights: int = 0, d_present: int = 0, d_status: int = 0, stream=None):
         _check(self.lib, self.lib.vet_spatial_entropy(self.handle, d_mu, d_mv, n_users, n_frames, d_entropy,
                                                       d_assign or None, d_weights or None, d_present or None,
-                                                      d_status or None, stream or None))
+                                                      d_status or None, _stream(stream)))
 
     def transition_device(self, d_mu: int, d_mv: int, n_users: int, n_frames: int, d_entropy: int, d_pairs: int = 0,
-                          d_srccount: int = 0, d_common: int = 0, d_status: int = 0, stream: int = 0):
+                          d_srccount: int = 0, d_common: int = 0, d_status: int = 0, stream=None):
         _check(self.lib, self.lib.vet_transition_entropy(self.handle, d_mu, d_mv, n_users, n_frames, d_entropy,
                                                          d_pairs or None, d_srccount or None, d_common or None,
-                                                         d_status or None, stream or None))
+                                                         d_status or None, _stream(stream)))
