@@ -60,6 +60,15 @@ def synth_video(U, T, seed, video_id, kind="random_walk"):
         cv = np.clip(0.5 + np.cumsum(rng.normal(0.0, 0.002, (T, 1)), axis=0), 0.2, 0.8)
         mu = np.mod(cu + rng.normal(0.0, 0.02, (T, U)), 1.0)
         mv = np.clip(cv + rng.normal(0.0, 0.02, (T, U)), 0.0, 1.0)
+    elif kind in ("uniform_half", "uniform_quarter"):   # diagnostic: uniform over a part of the sphere (table footprint)
+        frac = 0.5 if kind == "uniform_half" else 0.25
+        mu = rng.random((T, U))
+        mv = np.clip(np.arccos(1.0 - 2.0 * frac * rng.random((T, U))) / np.pi, 0.0, 1.0)
+    elif kind == "single":          # diagnostic: everybody in one direction (pure per-frame overhead)
+        mu, mv = np.full((T, U), 0.3), np.full((T, U), 0.4)
+    elif kind == "fixed":           # diagnostic: U distinct directions, the same in every frame (cache-hot rows)
+        mu = np.broadcast_to(rng.random((1, U)), (T, U)).copy()
+        mv = np.broadcast_to(np.clip(np.arccos(1.0 - 2.0 * rng.random((1, U))) / np.pi, 0.0, 1.0), (T, U)).copy()
     else:
         mu = np.mod(0.5 + np.cumsum(rng.normal(0.0, 0.01, (T, U)), axis=0), 1.0)
         mv = np.clip(0.5 + np.cumsum(rng.normal(0.0, 0.005, (T, U)), axis=0), 0.0, 1.0)
@@ -134,7 +143,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--data", default="random_walk", choices=["random_walk", "uniform", "clustered"],
+    ap.add_argument("--data", default="random_walk", choices=["random_walk", "uniform", "clustered", "single", "fixed", "uniform_half", "uniform_quarter"],
                     help="synthetic sample distribution (default: SURVEY §8d random walks)")
     ap.add_argument("--loop", action="store_true", help="batched workloads: one call per video instead of one launch")
     ap.add_argument("--shard", default="videos", choices=["videos", "frames"],

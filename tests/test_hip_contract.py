@@ -33,6 +33,11 @@ def all_directions():
     return mu, mv
 
 
+# The contract is relative (1e-6).  The absolute term only covers the FP64 rounding of the reference's own
+# evaluation: with p1 = 1 - O(1e-12) the term -p1*log2(p1) of entropy_utils.py:196-198 moves by 1.6e-16 per ulp
+# of p1, and numpy's and the device's log2 / summation order differ by such ulps (oracle vs the live
+# reference differ by as much: tests/golden was pinned at <= 1e-15).  It is 9 orders below an entropy of 1e-6.
+ATOL = 1e-15
 EXTREME = [([50], 30.0, 2.0), ([50], 120.0, 20.0), ([500], 5.0, 3.0), ([500], 10.0, 2.0), ([50], 120.0, 50.0)]
 _ORACLE = {}
 
@@ -66,13 +71,15 @@ def test_single_and_two_user_frames_over_all_directions(native, engine, tcs, fov
     for name, (mu, mv) in cases.items():
         res = plan.spatial(mu=mu, mv=mv)
         form = plan.last_formulation(0)
-        if (tcs, fov, power) in EXTREME[:2] + EXTREME[3:]:
-            assert form == "precise", (name, form, tab_bound, sweep_bound)    # integers cannot hold these
+        # an integer formulation only where the plan's own bound puts it inside the contract
+        table_asked = policy > 0 or (policy == 0 and mu.size >= 8 * (W + 1) * (H + 1))
+        want = "table" if (table_asked and tab_bound <= 1e-7) else ("sweep" if sweep_bound <= 1e-7 else "precise")
+        assert form == want, (name, form, tab_bound, sweep_bound)
         ent, assign = oracle_for(tcs, fov, power, name, mu, mv)
         assert np.array_equal(res["assign"], assign), name
         assert np.array_equal(np.isnan(res["entropy"]), np.isnan(ent)), name
         ok = ~np.isnan(ent)
-        np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=1e-6, atol=0, err_msg=f"{name} [{form}]")
+        np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=1e-6, atol=ATOL, err_msg=f"{name} [{form}]")
     plan.close()
 
 
@@ -99,7 +106,7 @@ def test_degenerate_lattices(native, engine, tcs, policy, fov, power):
     assert np.array_equal(res["assign"], assign)
     assert np.array_equal(np.isnan(res["entropy"]), np.isnan(ent)), (res["entropy"][:10], ent[:10])
     ok = ~np.isnan(ent)
-    np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=1e-6, atol=0)
+    np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=1e-6, atol=ATOL)
     np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=2.0 ** -33 * U)
     plan.close()
 

@@ -70,6 +70,6 @@ def test_hip_matches_oracle(native, engine, pr):
             np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=2.0 ** -32 * pr["U"] + 1e-12)
             ok = np.isfinite(ent)
             assert np.array_equal(np.isnan(res["entropy"]), np.isnan(ent))
-            np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=1e-8, atol=0)
+            np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=1e-8, atol=1e-15)
     finally:
         plan.close()

@@ -147,7 +147,7 @@ def test_extreme_entropy_configs(native, engine, fov, power, policy):
     np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=2.0 ** -32 * 60 + 1e-12)
     assert np.array_equal(np.isnan(res["entropy"]), np.isnan(ent))
     ok = np.isfinite(ent)
-    np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=1e-8, atol=0)
+    np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=1e-8, atol=1e-15)
     plan.close()
 
 

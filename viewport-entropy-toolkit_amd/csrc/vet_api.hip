@@ -484,6 +484,7 @@ int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& sr
     }
     q.entropy = d_entropy; q.assign = d_assign; q.weights = d_weights; q.present = d_present;
     q.status = d_status;
+    q.stage = env_int("VET_LUT_STAGE", 0, 9, 0);
     const bool dedup = (uint64_t)pl->n_dirs <= vet::DEDUP_MAX_DIRS && !getenv("VET_NO_DEDUP");
     int blocks = blocks_batch, threads = 256;
     size_t lds = lds_batch;
@@ -500,6 +501,7 @@ int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& sr
         q.FPW = fpw;
         blocks = (T + fpw - 1) / fpw;
         threads = env_threads("VET_LUT_THREADS", threads);
+        if (threads > 256) threads = 256;         // __launch_bounds__(256)
         occ8 = K == 1 && threads == 256;
     } else {
         q.FPW = 1; q.UC = 1;

@@ -794,6 +794,7 @@ struct LutParams {
     int32_t* present;
     int32_t* status;
     int FPW, UC;
+    int stage;                    // diagnostics: leave after stage N (0 = run everything)
 };
 
 // hash slots per frame: power of two >= 2 * UC, at least one wave's worth
@@ -889,6 +890,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
                 rows[(size_t)fl * UC + atomicAdd(&cnt_chunk[fl], 1)] = row;
             }
         }
+        if (p.stage == 1) return;
         __syncthreads();
         if (DEDUP) {
             // compact the sets into row lists; a wave's 64 slots belong to one frame (HS is a multiple of 64)
@@ -907,6 +909,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (on) rows[(size_t)fl * UC + base + below(m)] = v;
             }
+            if (p.stage == 2) return;
             __syncthreads();
             if (overlay)
                 for (int i = tid; i < FPW * p.n_sum; i += blockDim.x) hist[i] = 0ull;
@@ -936,6 +939,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
             hoff += L.n;
         }
     }
+    if (p.stage == 3) return;
     __syncthreads();
     // entropy (entropy_utils.py:194-211, weighted: normaliser log2 n); wave w takes frames w, w+NW, ...
     const double inv_unit = 1.0 / (4294967296.0 * (double)(1u << TAB_X));
