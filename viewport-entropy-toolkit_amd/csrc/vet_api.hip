@@ -75,6 +75,7 @@ struct vet_ctx {
 struct Lattice {
     int n = 0;
     double* d_tiles = nullptr;     // [n][3] unit
+    std::vector<double> h_unit;    // host copy of the unit tiles
     uint16_t* d_nearest = nullptr; // [n_dirs]
     double hmax = 0.0;
     // direction weight table (ELL), built on first use when the video has more samples than the
@@ -107,7 +108,8 @@ struct vet_plan {
     int weighted = 1;
     double cos_cull = 0.0;
     int table_policy = 0;          // 0 by call size, 1 table whenever it is inside the contract, -1 never
-    uint32_t* d_alias = nullptr;   // [n_dirs] direction id -> first id with the same Vector
+    uint32_t* d_alias = nullptr;   // [n_dirs] direction id -> table row | mirrored << 31 (ensure_alias)
+    bool mirror = false;           // rows are shared between mirror-image directions
 };
 
 namespace {
@@ -253,9 +255,14 @@ const void* lut_kernel(bool il, bool occ8, bool dedup) {
 constexpr size_t kMaxTableBytes = (size_t)24 << 30;   // per lattice; HBM is 288 GB
 constexpr double kContractMargin = 1e-7;              // bound on |dH|/H an integer formulation may have (contract: 1e-6)
 
-// direction id -> first id with the same Vector (value equality, -0.0 == 0.0): the pole row of a pixel
-// grid, the -180 -> 0 / -90 -> 0 remaps (utilities/data_utils.py:394-397) and 6-decimal collisions make
-// different pixels the same direction; they share one table row.
+// direction id -> table row.  Directions with the same Vector (value equality, -0.0 == 0.0) share a row:
+// the pole row of a pixel grid, the -180 -> 0 / -90 -> 0 remaps (utilities/data_utils.py:394-397) and
+// 6-decimal collisions make different pixels the same direction.  And the Fibonacci lattice is symmetric
+// under (x,y,z) -> (x,-y,-z) (tile i <-> tile n-1-i, utilities/data_utils.py:40-50: lat is odd in i, lon of -i
+// is 360 - lon of i), so when every lattice of the plan and the direction table have that symmetry BIT FOR
+// BIT, a direction and its mirror image share one row too, the mirrored one adding into tiles n-1-t: the
+// dot products d.t are then identical bit for bit, hence the weights.  Halves the table's cache footprint.
+// alias[d] = row | mirrored << 31.
 int ensure_alias(vet_plan* pl) {
     if (pl->d_alias) return VET_OK;
     const size_t D = (size_t)pl->n_dirs;
@@ -269,16 +276,39 @@ int ensure_alias(vet_plan* pl) {
             return (size_t)h;
         }
     };
+    auto key_of = [](double x, double y, double z) {
+        std::array<uint64_t, 3> key;
+        const double v[3] = {x + 0.0, y + 0.0, z + 0.0};    // -0.0 -> +0.0
+        memcpy(key.data(), v, 24);
+        return key;
+    };
     std::unordered_map<std::array<uint64_t, 3>, uint32_t, KeyHash> first;
     first.reserve(D * 2);
     std::vector<uint32_t> alias(D);
-    for (size_t d = 0; d < D; ++d) {
-        std::array<uint64_t, 3> key;
-        for (int c = 0; c < 3; ++c) {
-            const double v = raw[3 * d + c] + 0.0;          // -0.0 -> +0.0
-            memcpy(&key[c], &v, 8);
+    for (size_t d = 0; d < D; ++d)
+        alias[d] = first.emplace(key_of(raw[3 * d], raw[3 * d + 1], raw[3 * d + 2]), (uint32_t)d).first->second;
+    // mirror symmetry of every lattice, bit for bit on the unit vectors the kernels use
+    bool mirror = !getenv("VET_NO_MIRROR") && pl->weighted;
+    for (const auto& L : pl->lat) {
+        if (L.binned || L.h_unit.empty()) { mirror = false; break; }
+        for (int i = 0; i < L.n && mirror; ++i) {
+            const double* a = &L.h_unit[3 * (size_t)i];
+            const double* b = &L.h_unit[3 * (size_t)(L.n - 1 - i)];
+            mirror = a[0] == b[0] && a[1] == -b[1] && a[2] == -b[2];
         }
-        alias[d] = first.emplace(key, (uint32_t)d).first->second;
+        if (!mirror) break;
+    }
+    pl->mirror = mirror;
+    if (mirror) {
+        for (size_t d = 0; d < D; ++d) {
+            if (alias[d] != d) continue;                      // canonical rows only
+            const auto it = first.find(key_of(raw[3 * d], -raw[3 * d + 1], -raw[3 * d + 2]));
+            if (it != first.end() && it->second < d) alias[d] = it->second | 0x80000000u;
+        }
+        for (size_t d = 0; d < D; ++d) {                      // ids aliased to a mirrored row
+            const uint32_t a = alias[d];
+            if (!(a & 0x80000000u) && a != d) alias[d] = alias[a];
+        }
     }
     HIP_TRY(hipMalloc((void**)&pl->d_alias, D * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(pl->d_alias, alias.data(), D * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -905,6 +935,7 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
         PLAN_TRY(hipMemsetAsync(L.d_nearest + pl->n_dirs, 0, sizeof(uint16_t), s));
         PLAN_TRY(hipMemcpyAsync(L.d_tiles, unit.data(), unit.size() * sizeof(double), hipMemcpyHostToDevice, s));
         PLAN_TRY(hipStreamSynchronize(s));   // 'unit' goes out of scope
+        L.h_unit = unit;
         const size_t lds = (size_t)L.n * 3 * sizeof(double);
         if (lds > 160 * 1024 - 1024) return cleanup(fail(VET_ERR_UNSUPPORTED, "lattice of %d tiles exceeds the LDS tile cache", L.n));
         if (lds > 64 * 1024)

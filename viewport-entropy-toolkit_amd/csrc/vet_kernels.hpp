@@ -669,9 +669,12 @@ __global__ void k_wtab(const WtabParams p) {
 // row; UN rows per group are in flight; rows are zero padded, so a group walks to the longest of
 // its UN rows only.
 // ------------------------------------------------------------------------------------------
+constexpr int ROW_BITS = 19;
+constexpr uint32_t ROW_MASK = (1u << ROW_BITS) - 1;
+
 template <int UN, bool INTERLEAVED, bool DEDUP>
 __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t* fmeta, int nu,
-                                          unsigned long long* hrow,
+                                          unsigned long long* hrow, int n,
                                           const uint32_t* __restrict__ tab_w, const uint16_t* __restrict__ tab_i,
                                           int stride, int gs_log2, long zero_row) {
     // Every lane takes one 4-slot chunk per block: one 16-byte load of weights, one 8-byte load of
@@ -684,7 +687,8 @@ __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t*
     const int step = NW * UPW;
     for (int j0 = wv * UPW; j0 < nu; j0 += UN * step) {
         long row[UN];
-        int len[UN];
+        int len[UN], sgn[UN];
+        char* hb[UN];
         uint32_t mult[UN];
         int longest = 0;
 #pragma unroll
@@ -692,9 +696,15 @@ __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t*
             const int j = j0 + k * step + sub;
             const bool on = j < nu;
             const uint32_t pk = on ? frows[j] : 0u, m = on ? fmeta[j] : 0u;
-            row[k] = on ? (long)(DEDUP ? pk >> 12 : pk) * stride : zero_row;
+            const uint32_t key = DEDUP ? pk >> 12 : pk;
+            // a mirrored direction (x,-y,-z) walks its partner's row into the mirrored tiles n-1-t
+            const bool flip = ((DEDUP ? key >> ROW_BITS : key >> 31) & 1u) != 0u;
+            const uint32_t rid = DEDUP ? key & ROW_MASK : key & 0x7FFFFFFFu;
+            row[k] = on ? (long)rid * stride : zero_row;
             len[k] = (int)(m & 0xFFFFu);
             mult[k] = (DEDUP ? pk & 0xFFFu : (on ? 1u : 0u)) << (m >> 16);
+            sgn[k] = flip ? -8 : 8;
+            hb[k] = (char*)hrow + (flip ? (n - 1) * 8 : 0);
             longest = max(longest, len[k]);
         }
         // block base eb counts sorted entries; the lane's chunk sits at slots eb + 4*sl .. +3 and holds
@@ -728,10 +738,10 @@ __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t*
             }
 #pragma unroll
             for (int k = 0; k < UN; ++k) {
-                atomicAdd(&hrow[t[k].x], (unsigned long long)w[k].x * mult[k]);
-                atomicAdd(&hrow[t[k].y], (unsigned long long)w[k].y * mult[k]);
-                atomicAdd(&hrow[t[k].z], (unsigned long long)w[k].z * mult[k]);
-                atomicAdd(&hrow[t[k].w], (unsigned long long)w[k].w * mult[k]);
+                atomicAdd((unsigned long long*)(hb[k] + (int)t[k].x * sgn[k]), (unsigned long long)w[k].x * mult[k]);
+                atomicAdd((unsigned long long*)(hb[k] + (int)t[k].y * sgn[k]), (unsigned long long)w[k].y * mult[k]);
+                atomicAdd((unsigned long long*)(hb[k] + (int)t[k].z * sgn[k]), (unsigned long long)w[k].z * mult[k]);
+                atomicAdd((unsigned long long*)(hb[k] + (int)t[k].w * sgn[k]), (unsigned long long)w[k].w * mult[k]);
             }
         }
     }
@@ -756,7 +766,7 @@ __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t*
 // two such steps are issued back to back to keep more loads in flight.
 // ------------------------------------------------------------------------------------------
 constexpr int MAX_LATTICES = 8;
-constexpr unsigned DEDUP_MAX_DIRS = (1u << 20) - 1;      // row ids must fit 20 bits of a slot word
+constexpr unsigned DEDUP_MAX_DIRS = (1u << 19) - 1;      // set key = row (19 bits) | mirror flag; slot = key << 12 | count
 
 struct LutLattice {
     const uint32_t* tab_w;
@@ -784,7 +794,7 @@ struct LutParams {
     SampleSrc src;
     int U, T;
     const uint16_t* nearest;      // lattice 0 (assign)
-    const uint32_t* alias;        // [n_dirs] direction id -> canonical row
+    const uint32_t* alias;        // [n_dirs] direction id -> canonical row | mirrored << 31
     int K;                        // lattices handled by this launch (<= MAX_LATTICES)
     int n_sum;                    // sum of n over the K lattices
     LutLattice lat[MAX_LATTICES];
@@ -821,6 +831,7 @@ __host__ __device__ __forceinline__ size_t lut_lds_bytes(int U, int UC, int FPW,
 template <bool FROM_IDS, int UN, bool IL, bool OCC8, bool DEDUP>
 __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (p.stage == 9) return;
     // the video this workgroup works on: the launch's only one, or one of a batch
     SampleSrc src = p.src;
     int U = p.U, T = p.T, FPW = p.FPW, UC = p.UC;
@@ -867,54 +878,113 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
         if (DEDUP)
             for (int i = tid; i < FPW * HS; i += blockDim.x) hash[i] = EMPTY_KEY;
         __syncthreads();
-        for (int i = tid; i < nf * uc; i += blockDim.x) {
-            const int fl = i / uc, uu = i - fl * uc;
-            const long idx = (f0 + fl) * (long)U + u0 + uu;
-            const int id = sample_dir<FROM_IDS>(src, idx, bad);
-            if (assign) __builtin_nontemporal_store(id >= 0 ? (int)p.nearest[id] : -1, assign + idx);
-            if (id < 0) continue;
-            const uint32_t row = p.alias[id];
-            if (DEDUP) {
-                uint32_t* tab = hash + (size_t)fl * HS;
-                unsigned h = (row * 2654435761u) >> hs_shift;
-                for (;;) {
-                    unsigned cur = tab[h];
-                    if (cur == EMPTY_KEY) {
-                        cur = atomicCAS(&tab[h], EMPTY_KEY, (row << 12) | 1u);
-                        if (cur == EMPTY_KEY) break;
+        if (p.stage == 8) return;
+        // SPT samples per thread and round: all sample loads first, then the table gathers, then the LDS set
+        // inserts — three waves of independent requests instead of SPT dependent chains
+        constexpr int SPT = 4;
+        const int total = nf * uc;
+        for (int i0 = tid; i0 < total; i0 += SPT * (int)blockDim.x) {
+            int id[SPT], fls[SPT];
+            long idxs[SPT];
+            if (FROM_IDS) {
+#pragma unroll
+                for (int k = 0; k < SPT; ++k) {
+                    const int i = i0 + k * (int)blockDim.x;
+                    fls[k] = i / uc;
+                    idxs[k] = (f0 + fls[k]) * (long)U + u0 + (i - fls[k] * uc);
+                    id[k] = -1;
+                    if (i < total) {
+                        const int v = src.ids[idxs[k]];
+                        if (v >= src.n_dirs) bad = true; else if (v >= 0) id[k] = v;
                     }
-                    if ((cur >> 12) == row) { atomicAdd(&tab[h], 1u); break; }
-                    h = (h + 1) & (unsigned)(HS - 1);
                 }
             } else {
-                rows[(size_t)fl * UC + atomicAdd(&cnt_chunk[fl], 1)] = row;
+                double a[SPT], b[SPT];
+#pragma unroll
+                for (int k = 0; k < SPT; ++k) {
+                    const int i = i0 + k * (int)blockDim.x;
+                    fls[k] = i / uc;
+                    idxs[k] = (f0 + fls[k]) * (long)U + u0 + (i - fls[k] * uc);
+                    a[k] = b[k] = __builtin_nan("");
+                    if (i < total) {
+                        a[k] = __builtin_nontemporal_load(src.mu + idxs[k]);
+                        b[k] = __builtin_nontemporal_load(src.mv + idxs[k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < SPT; ++k) id[k] = grid_dir(a[k], b[k], src.W, src.H, bad);
+            }
+            uint32_t row[SPT];
+            int near[SPT];
+#pragma unroll
+            for (int k = 0; k < SPT; ++k) {
+                row[k] = 0u; near[k] = -1;
+                if (id[k] >= 0) {
+                    const uint32_t aw = p.alias[id[k]];        // canonical row | mirrored << 31
+                    row[k] = DEDUP ? (aw & ROW_MASK) | ((aw >> 31) << ROW_BITS) : aw;
+                    if (assign) near[k] = (int)p.nearest[id[k]];
+                }
+            }
+            if (assign) {
+#pragma unroll
+                for (int k = 0; k < SPT; ++k)
+                    if (i0 + k * (int)blockDim.x < total) __builtin_nontemporal_store(near[k], assign + idxs[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < SPT; ++k) {
+                const bool valid = id[k] >= 0;
+                const int fl = fls[k];
+                // users present per frame / new rows per frame: one LDS atomic per wave where the wave's
+                // samples belong to one frame (always when the user count is a multiple of 64)
+                const int fl0 = __builtin_amdgcn_readfirstlane(fl);
+                const bool uniform = __ballot(fl != fl0) == 0ull;
+                bool won = false;
+                unsigned h = 0;
+                if (DEDUP) {
+                    if (valid) {
+                        uint32_t* tab = hash + (size_t)fl * HS;
+                        h = (row[k] * 2654435761u) >> hs_shift;
+                        for (;;) {
+                            unsigned cur = tab[h];
+                            if (cur == EMPTY_KEY) {
+                                cur = atomicCAS(&tab[h], EMPTY_KEY, (row[k] << 12) | 1u);
+                                if (cur == EMPTY_KEY) { won = true; break; }
+                            }
+                            if ((cur >> 12) == row[k]) { atomicAdd(&tab[h], 1u); break; }
+                            h = (h + 1) & (unsigned)(HS - 1);
+                        }
+                    }
+                } else {
+                    won = valid;
+                }
+                const unsigned long long mv_ = __ballot(valid), mw = __ballot(won);
+                if (uniform) {
+                    int base = 0;
+                    if (lane == 0) {
+                        if (mv_) atomicAdd(&cnt_frame[fl0], (int)__popcll(mv_));
+                        if (mw) base = atomicAdd(&cnt_chunk[fl0], (int)__popcll(mw));
+                    }
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (won) rows[(size_t)fl0 * UC + base + below(mw)] = DEDUP ? h : row[k];
+                } else {
+                    if (valid) atomicAdd(&cnt_frame[fl], 1);
+                    if (won) rows[(size_t)fl * UC + atomicAdd(&cnt_chunk[fl], 1)] = DEDUP ? h : row[k];
+                }
             }
         }
         if (p.stage == 1) return;
         __syncthreads();
         if (DEDUP) {
-            // compact the sets into row lists; a wave's 64 slots belong to one frame (HS is a multiple of 64)
-            for (int s0 = wv * WAVE; s0 < FPW * HS; s0 += NW * WAVE) {
-                const int fl = s0 / HS;
-                const uint32_t v = hash[s0 + lane];
-                const bool on = v != EMPTY_KEY;
-                const unsigned long long m = __ballot(on);
-                if (m == 0ull) continue;
-                const int users = wave_sum(on ? (int)(v & 0xFFFu) : 0);
-                int base = 0;
-                if (lane == 0) {
-                    base = atomicAdd(&cnt_chunk[fl], (int)__popcll(m));
-                    atomicAdd(&cnt_frame[fl], users);
-                }
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (on) rows[(size_t)fl * UC + base + below(m)] = v;
+            // slot numbers -> slot words (row << 12 | multiplicity)
+            for (int i = tid; i < nf * UC; i += blockDim.x) {
+                const int fl = i / UC, j = i - fl * UC;
+                if (j < cnt_chunk[fl]) rows[i] = hash[(size_t)fl * HS + rows[i]];
             }
             if (p.stage == 2) return;
-            __syncthreads();
-            if (overlay)
+            if (overlay) {
+                __syncthreads();
                 for (int i = tid; i < FPW * p.n_sum; i += blockDim.x) hist[i] = 0ull;
-        } else {
-            for (int i = tid; i < FPW; i += blockDim.x) cnt_frame[i] += cnt_chunk[i];
+            }
         }
         int hoff = 0;
         for (int k = 0; k < p.K; ++k) {
@@ -924,17 +994,17 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
             if (k) __syncthreads();
             for (int i = tid; i < nf * UC; i += blockDim.x) {
                 const int fl = i / UC, j = i - fl * UC;
-                if (j < cnt_chunk[fl]) meta[i] = L.tab_meta[DEDUP ? rows[i] >> 12 : rows[i]];
+                if (j < cnt_chunk[fl]) meta[i] = L.tab_meta[DEDUP ? (rows[i] >> 12) & ROW_MASK : rows[i] & 0x7FFFFFFFu];
             }
             __syncthreads();
             for (int fl = 0; fl < nf; ++fl)
                 if (IL && L.interleaved)
                     walk_rows<UN, true, DEDUP>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
-                                               hist + (size_t)fl * p.n_sum + hoff, L.tab_w, L.tab_i, L.stride, L.gs_log2,
+                                               hist + (size_t)fl * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
                                                (long)src.n_dirs * L.stride);
                 else
                     walk_rows<UN, false, DEDUP>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
-                                                hist + (size_t)fl * p.n_sum + hoff, L.tab_w, L.tab_i, L.stride, L.gs_log2,
+                                                hist + (size_t)fl * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
                                                 (long)src.n_dirs * L.stride);
             hoff += L.n;
         }
