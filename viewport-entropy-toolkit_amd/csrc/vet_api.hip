@@ -110,6 +110,7 @@ struct vet_plan {
     int table_policy = 0;          // 0 by call size, 1 table whenever it is inside the contract, -1 never
     uint32_t* d_alias = nullptr;   // [n_dirs] direction id -> table row | mirrored << 31 (ensure_alias)
     bool mirror = false;           // rows are shared between mirror-image directions
+    uint2* d_dirrec = nullptr;     // [n_dirs] alias | nearest tile | lattice-0 row meta (k_dirrec), dedup-capable plans
 };
 
 namespace {
@@ -420,6 +421,12 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     }
     HIP_TRY(hipGetLastError());
     L.stride = stride;
+    if (k == 0 && (uint64_t)pl->n_dirs <= vet::DEDUP_MAX_DIRS) {
+        if (!pl->d_dirrec) HIP_TRY(hipMalloc((void**)&pl->d_dirrec, (size_t)pl->n_dirs * sizeof(uint2)));
+        hipLaunchKernelGGL(vet::k_dirrec, dim3(grid_for(pl->n_dirs, 256, c->n_cu)), dim3(256), 0, s, pl->d_alias,
+                           L.d_nearest, L.d_tab_meta, (long)pl->n_dirs, pl->d_dirrec);
+        HIP_TRY(hipGetLastError());
+    }
     return VET_OK;
 }
 
@@ -501,6 +508,8 @@ int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& sr
     q.src = src; q.U = U; q.T = T;
     q.nearest = pl->lat[lat_idx[0]].d_nearest;
     q.alias = pl->d_alias;
+    q.dirrec = pl->d_dirrec;
+    q.rec_meta = lat_idx[0] == 0 ? 1 : 0;
     q.K = K; q.n_sum = 0;
     bool il = false;
     for (int k = 0; k < K; ++k) {
@@ -515,7 +524,7 @@ int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& sr
     q.entropy = d_entropy; q.assign = d_assign; q.weights = d_weights; q.present = d_present;
     q.status = d_status;
     q.stage = env_int("VET_LUT_STAGE", 0, 9, 0);
-    const bool dedup = (uint64_t)pl->n_dirs <= vet::DEDUP_MAX_DIRS && !getenv("VET_NO_DEDUP");
+    const bool dedup = (uint64_t)pl->n_dirs <= vet::DEDUP_MAX_DIRS && pl->d_dirrec && !getenv("VET_NO_DEDUP");
     int blocks = blocks_batch, threads = 256;
     size_t lds = lds_batch;
     bool occ8 = true;
@@ -989,6 +998,7 @@ int vet_plan_destroy(vet_plan* pl) {
         if (L.d_row_s) (void)hipFree(L.d_row_s);
     }
     if (pl->d_alias) (void)hipFree(pl->d_alias);
+    if (pl->d_dirrec) (void)hipFree(pl->d_dirrec);
     delete pl;
     return VET_OK;
 }
@@ -1118,7 +1128,7 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
     std::vector<vet::VideoDesc>& desc = c->batch_desc;
     size_t lds_max = 0;
     if (table) {
-        const bool dedup = (uint64_t)pl->n_dirs <= vet::DEDUP_MAX_DIRS && !getenv("VET_NO_DEDUP");
+        const bool dedup = (uint64_t)pl->n_dirs <= vet::DEDUP_MAX_DIRS && pl->d_dirrec && !getenv("VET_NO_DEDUP");
         desc.resize(n_videos);
         int block = 0;
         for (int v = 0; v < n_videos && table; ++v) {

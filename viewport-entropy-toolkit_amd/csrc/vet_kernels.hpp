@@ -669,6 +669,17 @@ __global__ void k_wtab(const WtabParams p) {
 // row; UN rows per group are in flight; rows are zero padded, so a group walks to the longest of
 // its UN rows only.
 // ------------------------------------------------------------------------------------------
+// Per-direction record of the table kernel's prologue: one 8-byte gather per sample instead of three
+// (alias, nearest tile, row meta):  x = row (19 bits) | nearest tile bits 0..11 << 19 | mirrored << 31
+//                                     y = meta of the row in lattice 0 (21 bits) | nearest tile bits 12..15 << 21
+__global__ void k_dirrec(const uint32_t* __restrict__ alias, const uint16_t* __restrict__ nearest,
+                         const uint32_t* __restrict__ meta0, long D, uint2* __restrict__ rec) {
+    for (long d = blockIdx.x * (long)blockDim.x + threadIdx.x; d < D; d += (long)gridDim.x * blockDim.x) {
+        const uint32_t a = alias[d], near = nearest[d], row = a & 0x7FFFFu;
+        rec[d] = make_uint2(row | ((near & 0xFFFu) << 19) | (a & 0x80000000u), (meta0[row] & 0x1FFFFFu) | ((near >> 12) << 21));
+    }
+}
+
 constexpr int ROW_BITS = 19;
 constexpr uint32_t ROW_MASK = (1u << ROW_BITS) - 1;
 
@@ -795,6 +806,8 @@ struct LutParams {
     int U, T;
     const uint16_t* nearest;      // lattice 0 (assign)
     const uint32_t* alias;        // [n_dirs] direction id -> canonical row | mirrored << 31
+    const uint2* dirrec;          // [n_dirs] DEDUP: alias, nearest tile and lattice-0 meta in one 8-byte record (k_dirrec)
+    int rec_meta;                 // the record's meta word is that of this launch's first lattice
     int K;                        // lattices handled by this launch (<= MAX_LATTICES)
     int n_sum;                    // sum of n over the K lattices
     LutLattice lat[MAX_LATTICES];
@@ -914,15 +927,21 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
 #pragma unroll
                 for (int k = 0; k < SPT; ++k) id[k] = grid_dir(a[k], b[k], src.W, src.H, bad);
             }
-            uint32_t row[SPT];
+            uint32_t row[SPT], m0[SPT];
             int near[SPT];
 #pragma unroll
             for (int k = 0; k < SPT; ++k) {
-                row[k] = 0u; near[k] = -1;
+                row[k] = 0u; near[k] = -1; m0[k] = 0u;
                 if (id[k] >= 0) {
-                    const uint32_t aw = p.alias[id[k]];        // canonical row | mirrored << 31
-                    row[k] = DEDUP ? (aw & ROW_MASK) | ((aw >> 31) << ROW_BITS) : aw;
-                    if (assign) near[k] = (int)p.nearest[id[k]];
+                    if (DEDUP) {
+                        const uint2 rec = p.dirrec[id[k]];
+                        row[k] = (rec.x & ROW_MASK) | ((rec.x >> 31) << ROW_BITS);
+                        near[k] = (int)(((rec.x >> ROW_BITS) & 0xFFFu) | ((rec.y >> 21) << 12));
+                        m0[k] = rec.y & 0x1FFFFFu;
+                    } else {
+                        row[k] = p.alias[id[k]];                // canonical row | mirrored << 31
+                        if (assign) near[k] = (int)p.nearest[id[k]];
+                    }
                 }
             }
             if (assign) {
@@ -965,10 +984,18 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
                         if (mw) base = atomicAdd(&cnt_chunk[fl0], (int)__popcll(mw));
                     }
                     base = __builtin_amdgcn_readfirstlane(base);
-                    if (won) rows[(size_t)fl0 * UC + base + below(mw)] = DEDUP ? h : row[k];
+                    if (won) {
+                        const size_t pos = (size_t)fl0 * UC + base + below(mw);
+                        rows[pos] = DEDUP ? h : row[k];
+                        if (DEDUP) meta[pos] = m0[k];
+                    }
                 } else {
                     if (valid) atomicAdd(&cnt_frame[fl], 1);
-                    if (won) rows[(size_t)fl * UC + atomicAdd(&cnt_chunk[fl], 1)] = DEDUP ? h : row[k];
+                    if (won) {
+                        const size_t pos = (size_t)fl * UC + atomicAdd(&cnt_chunk[fl], 1);
+                        rows[pos] = DEDUP ? h : row[k];
+                        if (DEDUP) meta[pos] = m0[k];
+                    }
                 }
             }
         }
@@ -992,10 +1019,11 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
             // meta words (length, shift) of this lattice for every staged row: one parallel gather, so the
             // walk below has no dependent global load in front of its row loads
             if (k) __syncthreads();
-            for (int i = tid; i < nf * UC; i += blockDim.x) {
-                const int fl = i / UC, j = i - fl * UC;
-                if (j < cnt_chunk[fl]) meta[i] = L.tab_meta[DEDUP ? (rows[i] >> 12) & ROW_MASK : rows[i] & 0x7FFFFFFFu];
-            }
+            if (!(DEDUP && k == 0 && p.rec_meta))
+                for (int i = tid; i < nf * UC; i += blockDim.x) {
+                    const int fl = i / UC, j = i - fl * UC;
+                    if (j < cnt_chunk[fl]) meta[i] = L.tab_meta[DEDUP ? (rows[i] >> 12) & ROW_MASK : rows[i] & 0x7FFFFFFFu];
+                }
             __syncthreads();
             for (int fl = 0; fl < nf; ++fl)
                 if (IL && L.interleaved)
