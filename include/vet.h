@@ -208,6 +208,24 @@ int vet_transition_entropy_host(vet_plan *plan, const double *h_mu, const double
                                 double *h_entropy, int32_t *h_pairs, int32_t *h_srccount,
                                 int32_t *h_common);
 
+/* ---- host-buffer runs whose optional outputs stay on the device -----------------------------
+ * SpatialEntropyAnalyzer.compute_entropy returns per frame a dict of tile weights and a dict of tile
+ * assignments (analyzers/spatial_entropy.py:152-163) which most callers never read (the CSV holds time and
+ * entropy only, :216-219).  These variants bring back the entropy series (and the per-frame user counts)
+ * and keep assign [T][U] i32 + weights [T][n_0] f64 (transition: pairs [(T-1)][U][2] i32 + srccount
+ * [(T-1)][n_0] i32) in device memory owned by a vet_result, from which rows are fetched on demand.
+ * A result handle is returned also with VET_ERR_RANGE / VET_ERR_EMPTY. */
+typedef struct vet_result vet_result;
+int vet_spatial_entropy_host_resident(vet_plan *plan, const double *h_mu, const double *h_mv,
+                                      const int32_t *h_ids, int n_users, int n_frames,
+                                      double *h_entropy, int32_t *h_present, vet_result **out);
+int vet_transition_entropy_host_resident(vet_plan *plan, const double *h_mu, const double *h_mv,
+                                         const int32_t *h_ids, int n_users, int n_frames,
+                                         double *h_entropy, int32_t *h_common, vet_result **out);
+/* which: 0 = assignments / pairs, 1 = weights / source counts; rows [row0, row0 + n_rows) -> h_dst */
+int vet_result_fetch(vet_result *result, int which, int64_t row0, int64_t n_rows, void *h_dst);
+int vet_result_free(vet_result *result);
+
 /* ---- host-side track loader (no GPU involved) -------------------------------------------
  * Replaces the per-file `pd.read_csv(filepath)` + column selection of process_viewport_data
  * (utilities/data_utils.py:305-316) for a whole directory: the files are parsed on n_threads host

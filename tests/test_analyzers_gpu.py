@@ -232,3 +232,37 @@ def test_analyze_directories_single_process(tmp_path, golden_dir):
     assert sorted(got) == [0, 1]
     for v in got.values():
         np.testing.assert_allclose(v, g["w_tc50__entropy"], rtol=RTOL)
+
+
+def test_result_columns_are_fetched_from_the_device_on_access(tmp_path):
+    """compute_entropy brings back the entropy series only; tile_weights / tile_assignments cells are built from
+    device-resident rows when read, and equal the eager outputs of the engine (reference consumer:
+    analyzers/spatial_entropy.py:152-163)."""
+    from viewport_entropy_toolkit import AnalyzerConfig, SpatialEntropyAnalyzer, TransitionEntropyAnalyzer, _native, _synthetic
+    from viewport_entropy_toolkit._results import FrameDictArray
+    mu, mv = _synthetic.random_walk_video(40, 700, base_seed=31, p_absent=0.1)
+    mu[:, 0] = np.where(np.isnan(mu[:, 0]), 0.5, mu[:, 0])
+    mv[:, 0] = np.where(np.isnan(mv[:, 0]), 0.5, mv[:, 0])
+    times = np.arange(700) * 0.1
+    an = SpatialEntropyAnalyzer(AnalyzerConfig(tile_counts=[50, 100], output_dir=tmp_path))
+    an.load_arrays(times, mu, mv)
+    df = an.compute_entropy()
+    assert isinstance(df["tile_weights"].array, FrameDictArray) and len(df) == 700
+    eager = an._get_plan().spatial(mu=mu, mv=mv, want_assign=True, want_weights=True)
+    assert np.array_equal(df["entropy"].to_numpy(), eager["entropy"])
+    names = an._dense[3]
+    tiles = an._fibonacci_vectors[50]
+    for i in (0, 1, 255, 256, 257, 699, 300):
+        assert dict(df["tile_assignments"][i]) == {names[u]: int(t) for u, t in enumerate(eager["assign"][i]) if t >= 0}
+        assert dict(df.iloc[i]["tile_weights"]) == {tiles[t]: float(w) for t, w in enumerate(eager["weights"][i]) if w > 0}
+    assert sum(len(r["tile_assignments"]) for _, r in df.iloc[500:520].iterrows()) == int((eager["assign"][500:520] >= 0).sum())
+    tr = TransitionEntropyAnalyzer(AnalyzerConfig(tile_counts=[50], output_dir=tmp_path))
+    tr.load_arrays(times, mu, mv)
+    dt = tr.compute_entropy()
+    eager = tr._get_plan().transition(mu=mu, mv=mv, want_pairs=True, want_srccount=True)
+    assert np.array_equal(dt["entropy"].to_numpy(), eager["entropy"]) and len(dt) == 699
+    for i in (0, 300, 698):
+        assert dict(dt["tile_assignments"][i]) == {names[u]: (int(p), int(c)) for u, (p, c) in enumerate(eager["pairs"][i]) if p >= 0}
+        assert dict(dt["tile_weights"][i]) == {tiles[t]: int(k) for t, k in enumerate(eager["srccount"][i]) if k}
+    # the CSV the reference writes (time, entropy) needs no cell at all
+    df[["time", "entropy"]].to_csv(tmp_path / "x.csv", index=False)

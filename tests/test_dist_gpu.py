@@ -1,0 +1,141 @@
+"""GPU: the multi-GPU plumbing with the HIP engine as the per-rank compute (SURVEY.md §4 v):
+(i)  one rank under the `nccl` backend (= RCCL): `_dist.analyze_videos` / `transition_frame_sharded` go
+     through the RCCL branch of `gather_series` and equal the plain loop bit for bit;
+(ii) two ranks under `gloo`, both on device 0, each with its own engine context: videos sharded over the
+     ranks and one video cut along the frame axis equal the one-process result bit for bit;
+(iii) `bench.py --gpus 2` starts its own ranks (here rehearsed with the gloo backend on one device) and
+     reports n_gpus = 2."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+TCS = [50, 100]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _paths():
+    for p in (str(ROOT), str(ROOT / "viewport-entropy-toolkit_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _videos():
+    from viewport_entropy_toolkit import _synthetic
+    return [_synthetic.random_walk_video(24 + 8 * v, 90 + 11 * v, base_seed=21, video_id=v, p_absent=0.05) for v in range(5)]
+
+
+def _make_plans():
+    from viewport_entropy_toolkit import _native, _quantiser
+    eng = _native.Engine(0)
+    tiles = [_quantiser.lattice_xyz(tc) for tc in TCS]
+    spatial = _native.Plan(eng, tiles, 120.0, 2.0, True, 100, 200)
+    spatial.set_table_policy(1)
+    return eng, spatial
+
+
+def _worker(rank, world, port, q):
+    _paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from viewport_entropy_toolkit import _dist, _synthetic
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng, plan = _make_plans()
+        videos = _videos()
+        spatial = lambda v: plan.spatial(mu=v[0], mv=v[1], want_assign=False)["entropy"]          # noqa: E731
+        got = _dist.analyze_videos(videos, spatial)
+        mu, mv = _synthetic.random_walk_video(40, 203, base_seed=8)
+        trans = lambda a, b: plan.transition(mu=a, mv=b, want_pairs=False)["entropy"]             # noqa: E731
+        cut = _dist.transition_frame_sharded(mu, mv, trans)
+        if rank == 0:
+            ok_v = set(got) == set(range(len(videos))) and all(np.array_equal(got[v], spatial(videos[v])) for v in got)
+            ok_t = bool(np.array_equal(cut, trans(mu, mv)))
+            q.put((ok_v, ok_t))
+        plan.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_with_hip_compute():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    ok_v, ok_t = q.get(timeout=10)
+    assert ok_v, "videos sharded over two ranks differ from the one-process result"
+    assert ok_t, "frame-sharded transition entropy differs from the one-process result"
+
+
+def _rccl_worker(port, q):
+    _paths()
+    import torch
+    import torch.distributed as dist
+    from viewport_entropy_toolkit import _dist, _synthetic
+    torch.cuda.set_device(0)                       # torch's HIP runtime first, as in bench.py
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        assert dist.get_backend() == "nccl"
+        eng, plan = _make_plans()
+        videos = _videos()
+        spatial = lambda v: plan.spatial(mu=v[0], mv=v[1], want_assign=False)["entropy"]          # noqa: E731
+        got = _dist.analyze_videos(videos, spatial)
+        ok_v = set(got) == set(range(len(videos))) and all(np.array_equal(got[v], spatial(videos[v])) for v in got)
+        mu, mv = _synthetic.random_walk_video(40, 203, base_seed=8)
+        trans = lambda a, b: plan.transition(mu=a, mv=b, want_pairs=False)["entropy"]             # noqa: E731
+        ok_t = bool(np.array_equal(_dist.transition_frame_sharded(mu, mv, trans), trans(mu, mv)))
+        fixed = _dist.gather_series(np.arange(9.0), max_len=9)
+        ok_f = len(fixed) == 1 and bool(np.array_equal(fixed[0], np.arange(9.0)))
+        q.put((ok_v, ok_t, ok_f))
+        plan.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_rccl_gather():
+    """world_size 1 under the nccl backend (its own process, torch's runtime initialised first as in bench.py):
+    the gather of gather_series runs through RCCL on device buffers."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert q.get(timeout=10) == (True, True, True)
+
+
+@pytest.mark.parametrize("workload,shard", [("config2", "videos"), ("config5", "frames")])
+def test_bench_launches_its_own_ranks(workload, shard):
+    """`python bench.py --gpus 2` with no outer launcher: two ranks, n_gpus = 2 in the line (gloo rehearsal on
+    one device; the driver's multi-GPU runs use RCCL, one rank per GPU)."""
+    env = dict(os.environ, VET_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--workload", workload, "--shard", shard, "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["value"] > 0
+    assert rec["scaling"] == ("strong" if shard == "frames" else "weak")

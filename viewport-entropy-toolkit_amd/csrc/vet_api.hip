@@ -1190,8 +1190,15 @@ static int pooled(vet_ctx* c, int slot, size_t bytes, void** out) {
 }
 #define POOL(slot, bytes, var) do { int rc_ = pooled(c, slot, bytes, &var); if (rc_) return rc_; } while (0)
 
+struct vet_result {
+    vet_ctx* ctx = nullptr;
+    void* d[2] = {nullptr, nullptr};     // 0: assign / pairs, 1: weights / srccount
+    size_t row_bytes[2] = {0, 0};
+    int64_t rows = 0;
+};
+
 static int run_host(vet_plan* pl, bool transition, const double* h_mu, const double* h_mv, const int32_t* h_ids,
-                    int U, int T, double* h_entropy, int32_t* h_a, void* h_b, int32_t* h_c) {
+                    int U, int T, double* h_entropy, int32_t* h_a, void* h_b, int32_t* h_c, vet_result** keep = nullptr) {
     int rc = check_run_args(pl, U, T, h_entropy);
     if (rc) return rc;
     const bool ids = h_ids != nullptr;
@@ -1217,8 +1224,26 @@ static int run_host(vet_plan* pl, bool transition, const double* h_mu, const dou
     POOL(2, (size_t)(R > 0 ? R : 1) * 8, ent);
     const size_t a_bytes = transition ? (size_t)(R > 0 ? R : 0) * U * 2 * 4 : S * 4;
     const size_t b_bytes = transition ? (size_t)(R > 0 ? R : 0) * n0 * 4 : (size_t)T * n0 * 8;
-    if (h_a) POOL(3, a_bytes, a);
-    if (h_b) POOL(4, b_bytes, b);
+    vet_result* res = nullptr;
+    if (keep) {
+        // the optional outputs stay in device memory of their own, owned by the result handle
+        *keep = nullptr;
+        res = new vet_result();
+        res->ctx = c;
+        res->rows = R > 0 ? R : 0;
+        res->row_bytes[0] = transition ? (size_t)U * 2 * 4 : (size_t)U * 4;
+        res->row_bytes[1] = transition ? (size_t)n0 * 4 : (size_t)n0 * 8;
+        if (hipMalloc(&res->d[0], a_bytes ? a_bytes : 8) != hipSuccess || hipMalloc(&res->d[1], b_bytes ? b_bytes : 8) != hipSuccess) {
+            (void)hipGetLastError();
+            vet_result_free(res);
+            return fail(VET_ERR_DEVICE, "out of device memory for the resident outputs (%zu B)", a_bytes + b_bytes);
+        }
+        a = res->d[0]; b = res->d[1];
+    } else {
+        if (h_a) POOL(3, a_bytes, a);
+        if (h_b) POOL(4, b_bytes, b);
+    }
+    struct Guard { vet_result* r; ~Guard() { if (r) vet_result_free(r); } } guard{res};
     POOL(5, (size_t)(R > 0 ? R : 1) * 4, cc);
     POOL(6, 8, st);
     HIP_TRY(hipMemsetAsync(st, 0, 8, s));
@@ -1243,10 +1268,44 @@ static int run_host(vet_plan* pl, bool transition, const double* h_mu, const dou
         HIP_TRY(hipMemcpyAsync(status, st, 8, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(hipStreamSynchronize(s));
+    if (keep) { *keep = res; guard.r = nullptr; }       // outputs are written also when a status word is set
     if (status[0]) return fail(VET_ERR_RANGE, "Normalized coordinates must be between 0 and 1 (%d samples)", status[0]);
     if (status[1])
         return fail(VET_ERR_EMPTY, transition ? "%d frame pair(s) without a user present in both frames"
                                               : "%d frame(s) without any user (Empty vector dictionary)", status[1]);
+    return VET_OK;
+}
+
+int vet_spatial_entropy_host_resident(vet_plan* pl, const double* h_mu, const double* h_mv, const int32_t* h_ids, int U,
+                                      int T, double* h_entropy, int32_t* h_present, vet_result** out) {
+    if (!out) return fail(VET_ERR_INVALID, "out is NULL");
+    return run_host(pl, false, h_mu, h_mv, h_ids, U, T, h_entropy, nullptr, nullptr, h_present, out);
+}
+
+int vet_transition_entropy_host_resident(vet_plan* pl, const double* h_mu, const double* h_mv, const int32_t* h_ids,
+                                         int U, int T, double* h_entropy, int32_t* h_common, vet_result** out) {
+    if (!out) return fail(VET_ERR_INVALID, "out is NULL");
+    return run_host(pl, true, h_mu, h_mv, h_ids, U, T, h_entropy, nullptr, nullptr, h_common, out);
+}
+
+int vet_result_fetch(vet_result* r, int which, int64_t row0, int64_t n_rows, void* h_dst) {
+    if (!r || !h_dst) return fail(VET_ERR_INVALID, "result or destination is NULL");
+    if (which < 0 || which > 1) return fail(VET_ERR_INVALID, "which must be 0 (assignments / pairs) or 1 (weights / source counts)");
+    if (row0 < 0 || n_rows < 0 || row0 + n_rows > r->rows)
+        return fail(VET_ERR_INVALID, "rows [%lld, %lld) outside the result's %lld rows", (long long)row0,
+                    (long long)(row0 + n_rows), (long long)r->rows);
+    if (n_rows == 0) return VET_OK;
+    HIP_TRY(hipSetDevice(r->ctx->device));
+    HIP_TRY(hipMemcpy(h_dst, (const char*)r->d[which] + (size_t)row0 * r->row_bytes[which], (size_t)n_rows * r->row_bytes[which],
+                      hipMemcpyDeviceToHost));
+    return VET_OK;
+}
+
+int vet_result_free(vet_result* r) {
+    if (!r) return VET_OK;
+    if (r->ctx) (void)hipSetDevice(r->ctx->device);
+    for (void* q : r->d) if (q) (void)hipFree(q);
+    delete r;
     return VET_OK;
 }
 

@@ -45,7 +45,8 @@ def transition_frame_block(n_frames: int, rank: int, world: int) -> Tuple[int, i
 
 
 def gather_series(series: np.ndarray, dst: int = 0, max_len: Optional[int] = None, device=None):
-    """ONE gather of every rank's 1-D float64 series to ``dst``.
+    """ONE gather of every rank's 1-D float64 series to ``dst`` (through the process group's backend
+    whenever one is initialised, also for a world of one rank).
 
     The payload is ``[len, values..., padding]`` of a common size; ``max_len`` (known when all
     videos have the same number of frames) avoids the extra MAX all-reduce.  Returns the list
@@ -55,7 +56,7 @@ def gather_series(series: np.ndarray, dst: int = 0, max_len: Optional[int] = Non
     import torch.distributed as dist
 
     series = np.ascontiguousarray(series, dtype=np.float64).reshape(-1)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [series.copy()]
     world, rank = dist.get_world_size(), dist.get_rank()
     if device is not None:

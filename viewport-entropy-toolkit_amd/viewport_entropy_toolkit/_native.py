@@ -100,6 +100,10 @@ SIGNATURES = {
     "vet_spatial_entropy_batch_host": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "vet_spatial_entropy_host": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "vet_transition_entropy_host": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "vet_spatial_entropy_host_resident": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, C.POINTER(_P)]),
+    "vet_transition_entropy_host_resident": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, C.POINTER(_P)]),
+    "vet_result_fetch": (_I, [_P, _I, _I64, _I64, _P]),
+    "vet_result_free": (_I, [_P]),
     "vet_csv_read_tracks": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(Track), _I]),
     "vet_csv_free_tracks": (None, [_I, C.POINTER(Track)]),
 }
@@ -222,6 +226,33 @@ class Engine:
         ms, n = C.c_double(), C.c_int64()
         _check(self.lib, self.lib.vet_profile_get(self.handle, KERNEL_IDS[kernel], C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class DeviceResult:
+    """Optional outputs of one run, resident in device memory (include/vet.h: vet_result).  ``rows(which, r0, n)``
+    copies rows [r0, r0+n) of output ``which`` (0 = assignments / pairs, 1 = weights / source counts)."""
+
+    def __init__(self, lib, handle, n_rows, shapes, dtypes):
+        self.lib, self.handle, self.n_rows = lib, handle, int(n_rows)
+        self.shapes, self.dtypes = shapes, dtypes
+
+    def rows(self, which: int, row0: int, n: int) -> np.ndarray:
+        if self.handle is None:
+            raise RuntimeError("the device-resident result has been released")
+        out = np.empty((n,) + tuple(self.shapes[which]), dtype=self.dtypes[which])
+        _check(self.lib, self.lib.vet_result_fetch(self.handle, which, row0, n, _ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.vet_result_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 class Plan:
@@ -358,6 +389,38 @@ class Plan:
         if rc not in (VET_OK, VET_ERR_EMPTY, VET_ERR_RANGE) or (check and rc != VET_OK):
             _check(self.lib, rc)
         return dict(entropy=ent, pairs=pairs, srccount=src, common=common, code=rc)
+
+    def spatial_resident(self, mu=None, mv=None, ids=None, check=True):
+        """Like ``spatial`` but only entropy[T] and present[T] come back; the tile assignments and weights stay
+        on the device in ``result`` (a ``DeviceResult``) and are fetched by row on demand."""
+        mu, mv, ids, (T, U) = self._samples(mu, mv, ids)
+        ent = np.empty(T, dtype=np.float64)
+        present = np.empty(T, dtype=np.int32)
+        h = C.c_void_p()
+        rc = self.lib.vet_spatial_entropy_host_resident(self.handle, _ptr(mu), _ptr(mv), _ptr(ids), U, T, _ptr(ent),
+                                                        _ptr(present), C.byref(h))
+        result = DeviceResult(self.lib, h, T, [(U,), (self.n_tiles[0],)], [np.int32, np.float64]) if h.value else None
+        if rc not in (VET_OK, VET_ERR_EMPTY, VET_ERR_RANGE) or (check and rc != VET_OK):
+            if result is not None:
+                result.close()
+            _check(self.lib, rc)
+        return dict(entropy=ent, present=present, result=result, code=rc)
+
+    def transition_resident(self, mu=None, mv=None, ids=None, check=True):
+        """Like ``transition`` with the tile pairs and source-tile counts kept on the device."""
+        mu, mv, ids, (T, U) = self._samples(mu, mv, ids)
+        R = max(T - 1, 0)
+        ent = np.empty(R, dtype=np.float64)
+        common = np.empty(R, dtype=np.int32)
+        h = C.c_void_p()
+        rc = self.lib.vet_transition_entropy_host_resident(self.handle, _ptr(mu), _ptr(mv), _ptr(ids), U, T, _ptr(ent),
+                                                           _ptr(common), C.byref(h))
+        result = DeviceResult(self.lib, h, R, [(U, 2), (self.n_tiles[0],)], [np.int32, np.int32]) if h.value else None
+        if rc not in (VET_OK, VET_ERR_EMPTY, VET_ERR_RANGE) or (check and rc != VET_OK):
+            if result is not None:
+                result.close()
+            _check(self.lib, rc)
+        return dict(entropy=ent, common=common, result=result, code=rc)
 
     def spatial_batch(self, videos, want_assign=False, check=True):
         """Many videos, one launch.  ``videos``: sequence of (mu[T,U], mv[T,U]).  Returns a list of

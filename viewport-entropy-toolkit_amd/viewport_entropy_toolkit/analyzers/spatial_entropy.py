@@ -11,7 +11,7 @@ import pandas as pd
 
 from .. import _native
 from ..data_types import ValidationError
-from .._results import TileAssignments, TileWeights
+from .._results import DeviceRows, FrameDictArray, TileAssignments, TileWeights
 from ._base import _EntropyAnalyzerBase
 
 logger = logging.getLogger(__name__)
@@ -28,12 +28,14 @@ class SpatialEntropyAnalyzer(_EntropyAnalyzerBase):
         kind, times, a, b, names = self._samples()
         t_start = time.perf_counter()
         try:
+            # only the entropy series crosses PCIe; tile weights / assignments stay in device memory and are
+            # fetched by frame when a cell of the result is read
             if kind == "grid":
-                res = self._get_plan().spatial(mu=a, mv=b, want_assign=True, want_weights=True)
+                res = self._get_plan().spatial_resident(mu=a, mv=b)
             else:
                 plan = self._get_plan(dir_table=b)
                 try:
-                    res = plan.spatial(ids=a, want_assign=True, want_weights=True)
+                    res = plan.spatial_resident(ids=a)
                 finally:
                     plan.close()
         except _native.NativeError as e:
@@ -44,10 +46,12 @@ class SpatialEntropyAnalyzer(_EntropyAnalyzerBase):
             raise
         self._record_compute(time.perf_counter() - t_start, a.size, len(res["entropy"]))
         tiles = self._fibonacci_vectors[self.config.tile_counts[0]]
+        T = len(res["entropy"])
+        self._device_result = res["result"]
         self._entropy_results = pd.DataFrame({
             "time": times,
             "entropy": res["entropy"],
-            "tile_weights": [TileWeights(tiles, row) for row in res["weights"]],
-            "tile_assignments": [TileAssignments(names, row) for row in res["assign"]],
+            "tile_weights": FrameDictArray(DeviceRows(res["result"], 1, T), lambda row: TileWeights(tiles, row)),
+            "tile_assignments": FrameDictArray(DeviceRows(res["result"], 0, T), lambda row: TileAssignments(names, row)),
         })
         return self._entropy_results

@@ -12,7 +12,7 @@ import pandas as pd
 
 from .. import _native
 from ..data_types import ValidationError
-from .._results import TilePairs, TileWeights
+from .._results import DeviceRows, FrameDictArray, TilePairs, TileWeights
 from ._base import _EntropyAnalyzerBase
 
 logger = logging.getLogger(__name__)
@@ -29,11 +29,11 @@ class TransitionEntropyAnalyzer(_EntropyAnalyzerBase):
         t_start = time.perf_counter()
         try:
             if kind == "grid":
-                res = self._get_plan().transition(mu=a, mv=b, want_pairs=True, want_srccount=True)
+                res = self._get_plan().transition_resident(mu=a, mv=b)
             else:
                 plan = self._get_plan(dir_table=b)
                 try:
-                    res = plan.transition(ids=a, want_pairs=True, want_srccount=True)
+                    res = plan.transition_resident(ids=a)
                 finally:
                     plan.close()
         except _native.NativeError as e:
@@ -45,10 +45,12 @@ class TransitionEntropyAnalyzer(_EntropyAnalyzerBase):
             raise
         self._record_compute(time.perf_counter() - t_start, a.size, len(res["entropy"]))
         tiles = self._fibonacci_vectors[self.config.tile_counts[0]]
+        R = len(res["entropy"])
+        self._device_result = res["result"]
         self._entropy_results = pd.DataFrame({
             "time": times[1:],
             "entropy": res["entropy"],
-            "tile_weights": [TileWeights(tiles, row, as_int=True) for row in res["srccount"]],
-            "tile_assignments": [TilePairs(names, row) for row in res["pairs"]],
+            "tile_weights": FrameDictArray(DeviceRows(res["result"], 1, R), lambda row: TileWeights(tiles, row, as_int=True)),
+            "tile_assignments": FrameDictArray(DeviceRows(res["result"], 0, R), lambda row: TilePairs(names, row)),
         })
         return self._entropy_results
