@@ -64,13 +64,15 @@ def test_numeric_files_match_pandas_bit_for_bit(tmp_path, fmt, newline):
 
 
 def test_random_decimal_strings_convert_like_pandas(tmp_path):
-    """The converter itself: 60 000 random decimal spellings with 1-25 digits, signs, exponents."""
+    """The converter itself: 60 000 random decimal spellings with 1-25 digits, signs, exponents (integer
+    parts of at most 18 digits: beyond 64 bits pandas' dtype inference may keep the column as text, and the
+    loader hands such files to pandas — test_integer_parts_beyond_64_bits_are_left_to_pandas)."""
     rng = np.random.default_rng(99)
     toks = []
     for _ in range(60000):
         nd = int(rng.integers(1, 26))
         digits = "".join(rng.choice(list("0123456789"), nd))
-        cut = int(rng.integers(0, nd + 1))
+        cut = int(rng.integers(0, min(nd, 18) + 1))
         s = digits[:cut] + "." + digits[cut:]
         if s == ".":
             s = "0."
@@ -88,6 +90,22 @@ def test_random_decimal_strings_convert_like_pandas(tmp_path):
     assert status == _native.VET_CSV_OK
     for got, ref in zip(cols, pandas_columns(p)):
         assert same_bits(got, ref)
+
+
+@pytest.mark.parametrize("tok,ok", [
+    ("18446744073709551615e0", True), ("18446744073709551616e0", False), ("99999999999999999999.5", False),
+    ("-9223372036854775808.5", True), ("-9223372036854775809.5", False), ("0.5\n111111111111111111111.0", False),
+    ("00018446744073709551616.5", False), ("+9999999999999999999.5", True), ("0." + "9" * 30, True)])
+def test_integer_parts_beyond_64_bits_are_left_to_pandas(tmp_path, tok, ok):
+    """pandas tries int64, uint64, then float64 per column; an integer part that overflows both makes it keep the
+    column as text (found by the byte-level fuzz, tests/test_csv_loader_asan.py).  The fast path never answers for
+    such a file; what it does accept equals pandas bit for bit."""
+    p = write(tmp_path, "time,2dmu,2dmv\n" + "\n".join(f"{t},0.5,0.5" for t in tok.split("\n")) + "\n")
+    status, cols = native_columns(p)
+    assert (status == _native.VET_CSV_OK) == ok
+    if ok:
+        ref = pd.read_csv(p)
+        assert ref["time"].dtype == np.float64 and same_bits(cols[0], ref["time"].to_numpy())
 
 
 def test_missing_values_short_rows_blank_lines_and_bom(tmp_path):

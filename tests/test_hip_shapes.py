@@ -84,7 +84,8 @@ def test_other_pixel_grids(native, engine, W, H, tc, weighted):
     plan.close()
 
 
-@pytest.mark.parametrize("U,T,tcs", [(1500, 6, [50]), (4096, 3, [20]), (3, 30, [20, 50, 100]), (2, 2, [1000])])
+@pytest.mark.parametrize("U,T,tcs", [(1500, 6, [50]), (4096, 3, [20]), (3, 30, [20, 50, 100]), (2, 2, [1000]),
+                                     (9000, 3, [20]), (20000, 2, [200]), (5000, 4, [50, 20])])
 def test_transition_shapes(native, engine, U, T, tcs):
     mu, mv = video(U, T, seed=U + 7 * T, p_absent=0.05)
     mu[:, 0] = np.where(np.isnan(mu[:, 0]), 0.5, mu[:, 0])      # user 0 always present: no empty rows
@@ -95,6 +96,25 @@ def test_transition_shapes(native, engine, U, T, tcs):
     assert np.array_equal(res["pairs"], pairs)
     assert np.array_equal(res["common"], (~np.isnan(mu[1:]) & ~np.isnan(mu[:-1])).sum(1))
     np.testing.assert_allclose(res["entropy"], ent, rtol=1e-9, equal_nan=True)
+    plan.close()
+
+
+def test_transition_global_hash_variant_on_small_frames(native, engine, monkeypatch):
+    """The any-number-of-users variant of k_transition (bucket hash in global scratch, persistent workgroups)
+    forced onto ordinary shapes: same results as the LDS variant bit for bit, rows looped per workgroup."""
+    mu, mv = video(300, 700, seed=77, p_absent=0.1)
+    mu[:, 0] = np.where(np.isnan(mu[:, 0]), 0.5, mu[:, 0])
+    mv[:, 0] = np.where(np.isnan(mv[:, 0]), 0.5, mv[:, 0])
+    plan = plan_for(native, engine, [50, 200])
+    a = plan.transition(mu=mu, mv=mv, want_srccount=True)
+    monkeypatch.setenv("VET_T_GLOBAL", "1")
+    b = plan.transition(mu=mu, mv=mv, want_srccount=True)
+    monkeypatch.delenv("VET_T_GLOBAL")
+    for k in ("entropy", "pairs", "srccount", "common"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    ent, pairs = vo.transition_series(mu, mv, 100, 200, [50, 200])
+    assert np.array_equal(a["pairs"], pairs)
+    np.testing.assert_allclose(a["entropy"], ent, rtol=1e-9, equal_nan=True)
     plan.close()
 
 

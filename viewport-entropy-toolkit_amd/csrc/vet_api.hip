@@ -61,8 +61,8 @@ struct vet_ctx {
     size_t ws_bytes = 0;
     double* d_log2 = nullptr;      // log2(k), k = 0..4096
     // grow-only device staging buffers of the host-buffer entry points (no hipMalloc per call)
-    void* pool[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t pool_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void* pool[10] = {};
+    size_t pool_cap[10] = {};
     std::vector<vet::VideoDesc> batch_desc;   // host copy of the last batch's descriptors (kept alive)
     // profiling
     bool profiling = false;
@@ -71,6 +71,10 @@ struct vet_ctx {
     double prof_ms[KID_COUNT] = {};
     int64_t prof_n[KID_COUNT] = {};
 };
+
+extern "C" {
+static int pooled(vet_ctx* c, int slot, size_t bytes, void** out);   // slot-indexed grow-only device buffer
+}
 
 struct Lattice {
     int n = 0;
@@ -701,13 +705,15 @@ int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, dou
     }
     int HS = 64, lg = 6;
     while (HS < 2 * U) { HS <<= 1; ++lg; }
+    const size_t U4 = ((size_t)U + 3) & ~(size_t)3;
     for (int k = 0; k < K; ++k) {
         const Lattice& L = pl->lat[k];
-        size_t lds = 16 * 8 + 8 + (size_t)5 * L.n * 4 + (size_t)3 * HS * 4 + (size_t)U * 4 + 16;
+        const size_t n4 = ((size_t)L.n + 3) & ~(size_t)3;
+        const size_t lds_tiles = 16 + 4 * n4 * 4;
+        const size_t lds_run = lds_tiles + (size_t)3 * HS * 4;
         const size_t lds_cap = 160 * 1024 - 512;     // a single workgroup may take the whole LDS
-        if (lds > lds_cap)
-            return fail(VET_ERR_UNSUPPORTED, "transition kernel: %d users x %d tiles need %zu B of LDS (max %zu)", U,
-                        L.n, lds, lds_cap);
+        if (lds_tiles > lds_cap)
+            return fail(VET_ERR_UNSUPPORTED, "transition kernel: %d tiles need %zu B of LDS (max %zu)", L.n, lds_tiles, lds_cap);
         vet::TransParams p;
         p.src = src;
         p.U = U; p.T = T;
@@ -721,10 +727,41 @@ int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, dou
         p.status = k == 0 ? d_status : nullptr;
         p.HS = HS; p.hs_shift = 32 - lg;
         p.log2_tab = c->d_log2;
-        int threads = U > 1024 ? 512 : 256;      // measured: 256 is best at U = 512 (profiles/r01)
-        threads = env_threads("VET_T_THREADS", threads);
+        p.scratch = nullptr;
         ProfScope ps(c, s, KID_TRANSITION);
-        hipLaunchKernelGGL((vet::k_transition<FROM_IDS>), dim3(8 * ((R + 7) / 8)), dim3(threads), lds, s, p);
+        if (U <= 4096 && lds_run <= lds_cap && !getenv("VET_T_GLOBAL")) {
+            // persistent workgroups over contiguous runs of rows (k_transition_run); users per thread 1, 2, 4 or 8:
+            // two waves per row up to 512 users (measured: 46 us vs 51 us with four, profiles/r02)
+            int threads = U <= 512 ? 128 : (U <= 2048 ? 512 : 1024);
+            threads = env_threads("VET_T_THREADS", threads);
+            int upt = (U + threads - 1) / threads;
+            upt = upt <= 1 ? 1 : (upt <= 2 ? 2 : (upt <= 4 ? 4 : 8));
+            while ((long)upt * threads < U) threads *= 2;
+            long per_cu = (long)(lds_cap / lds_run);
+            const long by_waves = 32 / (threads / 64);
+            if (per_cu > by_waves) per_cu = by_waves;
+            per_cu = env_int("VET_T_WGS_PER_CU", 1, 16, (int)(per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu)));
+            long grid = (long)c->n_cu * per_cu;
+            if (grid > R) grid = R;
+            const void* fn = upt == 1 ? (const void*)vet::k_transition_run<FROM_IDS, 1>
+                           : upt == 2 ? (const void*)vet::k_transition_run<FROM_IDS, 2>
+                           : upt == 4 ? (const void*)vet::k_transition_run<FROM_IDS, 4>
+                                      : (const void*)vet::k_transition_run<FROM_IDS, 8>;
+            void* args[] = {(void*)&p};
+            HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(threads), args, lds_run, s));
+        } else {
+            // more users than the LDS holds: bucket hash and per-user words in global scratch, one slice per
+            // persistent workgroup (the reference accepts any number of users, entropy_utils.py:259-332)
+            const size_t slice = ((size_t)3 * HS + 2 * U4) * 4;
+            long grid = (long)c->n_cu * 2;
+            if (grid > R) grid = R;
+            while (grid > 1 && slice * (size_t)grid > ((size_t)2 << 30)) grid /= 2;
+            void* scratch = nullptr;
+            int rc = pooled(c, 8, slice * (size_t)grid, &scratch);
+            if (rc) return rc;
+            p.scratch = (uint32_t*)scratch;
+            hipLaunchKernelGGL((vet::k_transition_any<FROM_IDS>), dim3((unsigned)grid), dim3(1024), lds_tiles, s, p);
+        }
         HIP_TRY(hipGetLastError());
     }
     if (K > 1) {
@@ -976,8 +1013,14 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_transition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_transition<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+    {
+        const void* tk[] = {(const void*)vet::k_transition_run<false, 1>, (const void*)vet::k_transition_run<false, 2>,
+                            (const void*)vet::k_transition_run<false, 4>, (const void*)vet::k_transition_run<false, 8>,
+                            (const void*)vet::k_transition_run<true, 1>, (const void*)vet::k_transition_run<true, 2>,
+                            (const void*)vet::k_transition_run<true, 4>, (const void*)vet::k_transition_run<true, 8>,
+                            (const void*)vet::k_transition_any<false>, (const void*)vet::k_transition_any<true>};
+        for (const void* f : tk) PLAN_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+    }
 #undef PLAN_TRY
     *out = pl;
     return VET_OK;

@@ -56,11 +56,24 @@ int parse_field(const char* p, const char* end, double* out) {
     double number = 0.0;
     int exponent = 0, num_digits = 0, num_decimals = 0;
     bool any_digit = false, has_point = false, has_exp = false;
+    // pandas tries a column as int64, then uint64, before float64, and an integer part that overflows both
+    // makes it give up and keep the column as text (observed with pandas 2.3: 18446744073709551615e0 is a
+    // float, 18446744073709551616e0 and -9223372036854775809.5 are not; whether it happens depends on the
+    // rows before): leave every such file to pandas
+    const char* int_begin = p;
+    while (int_begin < end && *int_begin == '0') ++int_begin;
     while (p < end && is_digit(*p)) {
         any_digit = true;
         if (num_digits < kMaxDigits) { number = number * 10.0 + (double)(*p - '0'); ++num_digits; }
         else ++exponent;
         ++p;
+    }
+    {
+        static const char kU64Max[] = "18446744073709551615", kI64Min[] = "9223372036854775808";
+        const size_t int_len = p > int_begin ? (size_t)(p - int_begin) : 0;
+        const char* lim = negative ? kI64Min : kU64Max;
+        const size_t lim_len = negative ? 19 : 20;
+        if (int_len > lim_len || (int_len == lim_len && memcmp(int_begin, lim, lim_len) > 0)) return 2;
     }
     if (p < end && *p == '.') {
         has_point = true;

@@ -17,8 +17,10 @@
 //     k_spatial_u_lds  persistent stream with the nearest LUT in LDS (HBM-bound)
 //     k_spatial_u      generic fallback (LUT gathered from global memory)
 //   transition entropy
-//     k_transition     per frame pair: (prior tile, current tile) pairs -> bucket statistics in
-//                      LDS (integer atomics + one small hash table) -> transition entropy
+//     k_transition_run per frame pair: (prior tile, current tile) pairs -> bucket statistics in
+//                      LDS (integer atomics + one small hash table) -> transition entropy; persistent
+//                      workgroups over runs of rows, every frame quantised once
+//     k_transition_any the same for any number of users (bucket hash in global scratch)
 //   k_finalize         mean over the plan's lattices where they ran as separate launches
 //
 // No MFMA: there is no dense contraction on this path.  Reference citations are relative to
@@ -1373,113 +1375,57 @@ struct TransParams {
     const double* log2_tab;       // [4097] log2(k)
     int HS;                       // hash slots (power of two >= 2*U)
     int hs_shift;                 // 32 - log2(HS)
+    uint32_t* scratch;            // k_transition_any: per-workgroup slices of 3*HS + 2*U words
 };
 
-template <bool FROM_IDS>
-__global__ void k_transition(const TransParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* red = (double*)smem;                   // [16] per-wave partial sums
-    int* s_total = (int*)(red + 16);               // [2]
-    unsigned* first_u = (unsigned*)(s_total + 2);  // [n]
-    unsigned* m_cnt = first_u + p.n;               // [n]
-    unsigned* k_cnt = m_cnt + p.n;                 // [n]
-    unsigned* last_fu = k_cnt + p.n;               // [n]
-    unsigned* w_last = last_fu + p.n;              // [n]
-    unsigned* hkey = w_last + p.n;                 // [HS]
-    unsigned* hfu = hkey + p.HS;                   // [HS]
-    unsigned* hcnt = hfu + p.HS;                   // [HS]
-    unsigned* pc = hcnt + p.HS;                    // [U]
+// Per-tile words of one row in LDS (both transition kernels):
+//   acc u64 [2] (fixed-point entropy sum, users in both frames) | first_u, m_cnt, k_cnt, last_fu u32 [n4]
+// Row algorithm:
+//   (1) every user: tiles of both frames, key = p << 16 | c, first_u[p] = min u, m[p] += 1
+//   (2) non-first users: bucket insert (CAS); the creator of a bucket counts it into K[p];
+//       bucket first-user = min u, bucket count += 1; the user remembers its slot
+//   (3) non-first users that are the first of their bucket: last_fu[p] = max u
+//   (4) the user last_fu[p] publishes w[p] = its bucket's count (into first_u[p], free by then)
+//   (5) per tile: cell = -(m/N) K (w/m) log2(w/m) = -(K w / N)(log2 w - log2 m); the cells are summed as
+//       64-bit fixed point (2^-46) with ONE LDS atomic per wave instruction: order independent, hence
+//       the same bits from every kernel variant, workgroup size and GPU count
+constexpr double TRANS_FX = 70368744177664.0;    // 2^46: cells <= 12 * U < 2^16
 
-    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id(), NW = blockDim.x >> 6;
-    // output row r compares frames r (prior) and r+1 (current).  Frame r+1 is read again by row
-    // r+1: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous run of
-    // rows — the second read then comes from that XCD's L2 (placement only affects speed).
-    const long rows_per_xcd = (p.T - 1 + 7) / 8;
-    const long r = (long)(blockIdx.x & 7) * rows_per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= rows_per_xcd || r >= p.T - 1) return;
-    for (int i = tid; i < p.n; i += blockDim.x) {
-        first_u[i] = 0xFFFFFFFFu; m_cnt[i] = 0; k_cnt[i] = 0; last_fu[i] = 0; w_last[i] = 0;
+__device__ __forceinline__ void trans_init(unsigned* tile_words, int n4, unsigned* hkey, unsigned* hfu, unsigned* hcnt, int HS,
+                                           unsigned long long* acc) {
+    const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u), zeros = make_uint4(0u, 0u, 0u, 0u);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n4 / 4; i += blockDim.x) {
+        ((uint4*)tile_words)[i] = ones;                                   // first_u
+        ((uint4*)tile_words)[i + n4 / 4] = zeros;                         // m_cnt
+        ((uint4*)tile_words)[i + 2 * (n4 / 4)] = zeros;                   // k_cnt
+        ((uint4*)tile_words)[i + 3 * (n4 / 4)] = zeros;                   // last_fu
     }
-    for (int i = tid; i < p.HS; i += blockDim.x) { hkey[i] = EMPTY_KEY; hfu[i] = 0xFFFFFFFFu; hcnt[i] = 0; }
-    if (tid == 0) s_total[0] = 0;
-    __syncthreads();
+    for (int i = tid; i < HS / 4; i += blockDim.x) {
+        ((uint4*)hkey)[i] = ones; ((uint4*)hfu)[i] = ones; ((uint4*)hcnt)[i] = zeros;
+    }
+    if (tid == 0) { acc[0] = 0ull; acc[1] = 0ull; }
+}
 
-    bool bad = false;
-    int mine = 0;
-    for (int u = tid; u < p.U; u += blockDim.x) {
-        // cached loads here: frame r+1 is read again by row r+1 of the same XCD
-        const int ia = sample_dir<FROM_IDS, false>(p.src, r * (long)p.U + u, bad);
-        const int ib = sample_dir<FROM_IDS, false>(p.src, (r + 1) * (long)p.U + u, bad);
-        unsigned packed = EMPTY_KEY;
-        int pa = -1, cb = -1;
-        if (ia >= 0 && ib >= 0) {           // user present in both frames (entropy_utils.py:259-261)
-            pa = p.nearest[ia]; cb = p.nearest[ib];
-            packed = ((unsigned)pa << 16) | (unsigned)cb;
-            atomicMin(&first_u[pa], (unsigned)u);
-            atomicAdd(&m_cnt[pa], 1u);
-            ++mine;
-        }
-        pc[u] = packed;
-        if (p.pairs) {      // written once: non-temporal
-            __builtin_nontemporal_store(pa, p.pairs + (r * (long)p.U + u) * 2);
-            __builtin_nontemporal_store(cb, p.pairs + (r * (long)p.U + u) * 2 + 1);
-        }
-    }
-    mine = wave_sum(mine);
-    if (lane == 0 && mine) atomicAdd(&s_total[0], mine);
-    __syncthreads();
-    const int N = s_total[0];
-
-    // buckets of the non-first users of each source tile
-    for (int u = tid; u < p.U; u += blockDim.x) {
-        const unsigned key = pc[u];
-        if (key == EMPTY_KEY) continue;
-        if (first_u[key >> 16] == (unsigned)u) continue;
-        unsigned h = (key * 2654435761u) >> p.hs_shift;
-        for (;;) {
-            const unsigned prev = atomicCAS(&hkey[h], EMPTY_KEY, key);
-            if (prev == EMPTY_KEY || prev == key) break;
-            h = (h + 1) & (unsigned)(p.HS - 1);
-        }
-        atomicMin(&hfu[h], (unsigned)u);
-        atomicAdd(&hcnt[h], 1u);
-    }
-    __syncthreads();
-    for (int s = tid; s < p.HS; s += blockDim.x) {
-        const unsigned key = hkey[s];
-        if (key == EMPTY_KEY) continue;
-        atomicAdd(&k_cnt[key >> 16], 1u);
-        atomicMax(&last_fu[key >> 16], hfu[s]);
-    }
-    __syncthreads();
-    for (int s = tid; s < p.HS; s += blockDim.x) {
-        const unsigned key = hkey[s];
-        if (key == EMPTY_KEY) continue;
-        if (hfu[s] == last_fu[key >> 16]) w_last[key >> 16] = hcnt[s];
-    }
-    __syncthreads();
-
-    // cell = -(m/N) * K * (w/m) * log2(w/m) = -(K w / N) (log2 w - log2 m): m cancels, and the
-    // logarithms of the integer counts come from the per-context table (U <= 4096)
-    double h = 0.0;
-    const double inv_n = 1.0 / (double)N;
-    const bool tab = p.U <= 4096;
+// step (5) and the row's outputs; all threads call it after step (4) is visible
+__device__ __forceinline__ void trans_cells(const TransParams& p, long r, const unsigned* first_u, const unsigned* m_cnt,
+                                            const unsigned* k_cnt, unsigned long long* acc, bool tab) {
+    const int tid = threadIdx.x;
+    const int N = (int)acc[1];
     for (int t = tid; t < p.n; t += blockDim.x) {
         const unsigned m = m_cnt[t];
         if (m) {
             const unsigned K = 1u + k_cnt[t];
-            const unsigned w = (m == 1u) ? 1u : w_last[t];
+            const unsigned w = (m == 1u) ? 1u : first_u[t];
             const double lq = tab ? p.log2_tab[w] - p.log2_tab[m] : log2((double)w / (double)m);
-            h -= ((double)(K * w) * inv_n) * lq;
+            const double cell = -(double)((unsigned long long)K * w) * lq;
+            if (cell > 0.0) atomicAdd(&acc[0], (unsigned long long)rint(cell * TRANS_FX));
         }
         if (p.srccount) p.srccount[r * (long)p.n + t] = (int)m;
     }
-    h = wave_sum(h);
-    if (lane == 0) red[wv] = h;
     __syncthreads();
     if (tid == 0) {
-        double tot = 0.0;
-        for (int i = 0; i < NW; ++i) tot += red[i];
+        const double tot = (double)acc[0] / TRANS_FX / (double)N;
         double hmax = p.hmax;
         if (!(N > p.n)) {
             const double tp = 1.0 / (double)N;          // entropy_utils.py:322-327
@@ -1492,6 +1438,225 @@ __global__ void k_transition(const TransParams p) {
         }
         p.ent_k[r] = e;
         if (p.common) p.common[r] = N;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_transition_any — compute_transition_entropy (entropy_utils.py:213-332) for ANY number of users:
+// the bucket hash and the per-user words live in a per-workgroup slice of global scratch (L2
+// resident), persistent workgroups loop over the rows; only the per-tile words stay in LDS.
+// For source tile p with m users in column order a_1 < ... < a_m the reference's dict walk reduces to
+// (pinned by oracle/vet_oracle.py):
+//   K = 1 + #distinct destinations among a_2..a_m        (a_1 sits alone in an int-keyed bucket)
+//   w = 1 if m == 1 else count among a_2..a_m of the destination whose first appearance is
+//       latest                                           (stale loop variable, :307-315)
+//   cell = -(m/N) * K * (w/m) * log2(w/m),  H = sum cell,  normalised by log2(n) if N > n else log2(N).
+// ------------------------------------------------------------------------------------------
+template <bool FROM_IDS>
+__global__ void k_transition_any(const TransParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* acc = (unsigned long long*)smem;       // [2]
+    unsigned* first_u = (unsigned*)(acc + 2);                  // [n4]
+    const int n4 = (p.n + 3) & ~3;
+    unsigned* m_cnt = first_u + n4;
+    unsigned* k_cnt = m_cnt + n4;
+    unsigned* last_fu = k_cnt + n4;
+    const int tid = threadIdx.x, lane = lane_id();
+    const size_t U4 = ((size_t)p.U + 3) & ~(size_t)3;
+    unsigned* hkey = p.scratch + (size_t)blockIdx.x * (3 * (size_t)p.HS + 2 * U4);   // [HS]
+    unsigned* hfu = hkey + p.HS;                   // [HS]
+    unsigned* hcnt = hfu + p.HS;                   // [HS]
+    unsigned* pc = hcnt + p.HS;                    // [U4] the packed pairs
+    unsigned* uslot = pc + U4;                     // [U4] bucket slot of every non-first user
+    const long R = (long)p.T - 1;
+    const bool tab = p.U <= 4096;
+    bool bad = false;
+    for (long r = blockIdx.x; r < R; r += gridDim.x) {
+        __syncthreads();                           // previous row fully consumed
+        trans_init(first_u, n4, hkey, hfu, hcnt, p.HS, acc);
+        __syncthreads();
+        for (int u = tid; u < p.U; u += blockDim.x) {
+            const int ia = sample_dir<FROM_IDS, false>(p.src, r * (long)p.U + u, bad);
+            const int ib = sample_dir<FROM_IDS, false>(p.src, (r + 1) * (long)p.U + u, bad);
+            unsigned packed = EMPTY_KEY;
+            int pa = -1, cb = -1;
+            if (ia >= 0 && ib >= 0) {           // user present in both frames (entropy_utils.py:259-261)
+                pa = p.nearest[ia]; cb = p.nearest[ib];
+                packed = ((unsigned)pa << 16) | (unsigned)cb;
+                atomicMin(&first_u[pa], (unsigned)u);
+                atomicAdd(&m_cnt[pa], 1u);
+            }
+            const unsigned long long both = __ballot(packed != EMPTY_KEY);
+            if (lane == 0 && both) atomicAdd(&acc[1], (unsigned long long)__popcll(both));
+            pc[u] = packed;
+            if (p.pairs) {      // written once: non-temporal
+                __builtin_nontemporal_store(pa, p.pairs + (r * (long)p.U + u) * 2);
+                __builtin_nontemporal_store(cb, p.pairs + (r * (long)p.U + u) * 2 + 1);
+            }
+        }
+        __syncthreads();
+        for (int u = tid; u < p.U; u += blockDim.x) {
+            const unsigned key = pc[u];
+            unsigned mark = 0x40000000u;              // absent, or the first user of its source tile
+            if (key != EMPTY_KEY && first_u[key >> 16] != (unsigned)u) {
+                unsigned h = (key * 2654435761u) >> p.hs_shift;
+                for (;;) {
+                    const unsigned prev = atomicCAS(&hkey[h], EMPTY_KEY, key);
+                    if (prev == EMPTY_KEY) { atomicAdd(&k_cnt[key >> 16], 1u); break; }      // a new destination of this source tile
+                    if (prev == key) break;
+                    h = (h + 1) & (unsigned)(p.HS - 1);
+                }
+                atomicMin(&hfu[h], (unsigned)u);
+                atomicAdd(&hcnt[h], 1u);
+                mark = h;
+            }
+            uslot[u] = mark;
+        }
+        __syncthreads();
+        for (int u = tid; u < p.U; u += blockDim.x) {
+            const unsigned sl = uslot[u];
+            if (sl < 0x40000000u && hfu[sl] == (unsigned)u) atomicMax(&last_fu[pc[u] >> 16], (unsigned)u);
+        }
+        __syncthreads();
+        // the user last_fu[p] publishes w[p] = its bucket's count into first_u[p] (nobody reads first_u any more)
+        for (int u = tid; u < p.U; u += blockDim.x) {
+            const unsigned sl = uslot[u];
+            if (sl < 0x40000000u && last_fu[pc[u] >> 16] == (unsigned)u) first_u[pc[u] >> 16] = hcnt[sl];
+        }
+        __syncthreads();
+        trans_cells(p, r, first_u, m_cnt, k_cnt, acc, tab);
+    }
+    if (p.status) {
+        const unsigned long long anybad = __ballot(bad);
+        if (anybad && lane == 0) atomicAdd(&p.status[0], (int)__popcll(anybad));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_transition_run — the same rows for U <= UPT * blockDim users (everything in LDS), software
+// pipelined: a persistent workgroup takes a contiguous RUN of rows.  The current frame's tiles of row r
+// stay in registers as the prior frame's tiles of row r+1 (every frame is read and quantised once
+// instead of twice), and the samples of frame r+2 are requested before the bucket phases of row r, so
+// the HBM latency hides behind LDS work.  Thread t owns users t, t + blockDim, ...  The kernel is
+// bound by instruction issue, and the per-row fixed work (initialisation, barriers, the tile phase) is
+// paid per wave: two waves with four users per lane measured best at 512 users.
+// ------------------------------------------------------------------------------------------
+template <bool FROM_IDS, int UPT>
+__global__ void k_transition_run(const TransParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* acc = (unsigned long long*)smem;       // [2]
+    unsigned* first_u = (unsigned*)(acc + 2);                  // [n4]
+    const int n4 = (p.n + 3) & ~3;
+    unsigned* m_cnt = first_u + n4;
+    unsigned* k_cnt = m_cnt + n4;
+    unsigned* last_fu = k_cnt + n4;
+    unsigned* hkey = last_fu + n4;                 // [HS]
+    unsigned* hfu = hkey + p.HS;
+    unsigned* hcnt = hfu + p.HS;
+    const int tid = threadIdx.x, lane = lane_id();
+    const long R = (long)p.T - 1;
+    const long r_begin = R * (long)blockIdx.x / gridDim.x, r_end = R * ((long)blockIdx.x + 1) / gridDim.x;
+    if (r_begin >= r_end) return;
+    bool bad = false;
+    int prev[UPT], cur[UPT];
+    double sa[UPT], sb[UPT];                       // samples of the frame after the current one, in flight
+    int si[UPT];
+    bool mine[UPT];
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) mine[k] = tid + k * (int)blockDim.x < p.U;
+    auto request = [&](long f) {                   // issue the loads of frame f
+        const long base = f * (long)p.U + tid;
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) {
+            if (FROM_IDS) si[k] = mine[k] ? p.src.ids[base + k * (int)blockDim.x] : -1;
+            else {
+                sa[k] = sb[k] = __builtin_nan("");
+                if (mine[k]) { sa[k] = p.src.mu[base + k * (int)blockDim.x]; sb[k] = p.src.mv[base + k * (int)blockDim.x]; }
+            }
+        }
+    };
+    auto tiles_of = [&](int* out) {                // requested samples -> direction ids -> nearest tiles (-1 absent)
+        int id[UPT];
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) {
+            if (FROM_IDS) {
+                id[k] = -1;
+                if (si[k] >= p.src.n_dirs) bad = true; else if (si[k] >= 0) id[k] = si[k];
+            } else {
+                id[k] = grid_dir(sa[k], sb[k], p.src.W, p.src.H, bad);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) out[k] = id[k] >= 0 ? (int)p.nearest[id[k]] : -1;
+    };
+    request(r_begin);
+    tiles_of(prev);
+    request(r_begin + 1);
+    int32_t* pairs_row = p.pairs ? p.pairs + (r_begin * (long)p.U + tid) * 2 : nullptr;
+    for (long r = r_begin; r < r_end; ++r) {
+        trans_init(first_u, n4, hkey, hfu, hcnt, p.HS, acc);      // the previous row's last barrier precedes
+        tiles_of(cur);
+        if (r + 1 < r_end) request(r + 2);         // in flight during this row's LDS phases
+        __syncthreads();
+        unsigned key[UPT];
+        int present = 0;
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) {
+            const unsigned u = (unsigned)(tid + k * (int)blockDim.x);
+            key[k] = EMPTY_KEY;
+            const bool both = prev[k] >= 0 && cur[k] >= 0;      // present in both frames (entropy_utils.py:259-261)
+            if (both) {
+                key[k] = ((unsigned)prev[k] << 16) | (unsigned)cur[k];
+                atomicMin(&first_u[prev[k]], u);
+                atomicAdd(&m_cnt[prev[k]], 1u);
+            }
+            present += (int)__popcll(__ballot(both));
+            if (pairs_row && mine[k]) {
+                __builtin_nontemporal_store(both ? prev[k] : -1, pairs_row + 2 * k * (int)blockDim.x);
+                __builtin_nontemporal_store(both ? cur[k] : -1, pairs_row + 2 * k * (int)blockDim.x + 1);
+            }
+        }
+        if (pairs_row) pairs_row += 2 * (long)p.U;
+        if (lane == 0 && present) atomicAdd(&acc[1], (unsigned long long)present);
+        __syncthreads();
+        unsigned slot[UPT];
+        bool nonfirst[UPT];
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) {
+            const unsigned u = (unsigned)(tid + k * (int)blockDim.x);
+            nonfirst[k] = key[k] != EMPTY_KEY && first_u[key[k] >> 16] != u;
+            slot[k] = 0;
+            if (nonfirst[k]) {
+                unsigned h = (key[k] * 2654435761u) >> p.hs_shift;
+                for (;;) {
+                    const unsigned was = atomicCAS(&hkey[h], EMPTY_KEY, key[k]);
+                    if (was == EMPTY_KEY) { atomicAdd(&k_cnt[key[k] >> 16], 1u); break; }
+                    if (was == key[k]) break;
+                    h = (h + 1) & (unsigned)(p.HS - 1);
+                }
+                atomicMin(&hfu[h], u);
+                atomicAdd(&hcnt[h], 1u);
+                slot[k] = h;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) {
+            const unsigned u = (unsigned)(tid + k * (int)blockDim.x);
+            if (nonfirst[k] && hfu[slot[k]] == u) atomicMax(&last_fu[key[k] >> 16], u);
+        }
+        __syncthreads();
+        // w of a source tile = count of the bucket whose first user is last_fu: that user publishes it
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) {
+            const unsigned u = (unsigned)(tid + k * (int)blockDim.x);
+            if (nonfirst[k] && last_fu[key[k] >> 16] == u) first_u[key[k] >> 16] = hcnt[slot[k]];   // first_u is free now
+        }
+        __syncthreads();
+        trans_cells(p, r, first_u, m_cnt, k_cnt, acc, true);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) prev[k] = cur[k];
     }
     if (p.status) {
         const unsigned long long anybad = __ballot(bad);
