@@ -101,7 +101,7 @@ def test_transition_shapes(native, engine, U, T, tcs):
 
 def test_transition_global_hash_variant_on_small_frames(native, engine, monkeypatch):
     """The any-number-of-users variant of k_transition (bucket hash in global scratch, persistent workgroups)
-    forced onto ordinary shapes: same results as the LDS variant bit for bit, rows looped per workgroup."""
+    forced onto ordinary shapes: same results as the LDS variant, rows looped per workgroup."""
     mu, mv = video(300, 700, seed=77, p_absent=0.1)
     mu[:, 0] = np.where(np.isnan(mu[:, 0]), 0.5, mu[:, 0])
     mv[:, 0] = np.where(np.isnan(mv[:, 0]), 0.5, mv[:, 0])
@@ -110,8 +110,9 @@ def test_transition_global_hash_variant_on_small_frames(native, engine, monkeypa
     monkeypatch.setenv("VET_T_GLOBAL", "1")
     b = plan.transition(mu=mu, mv=mv, want_srccount=True)
     monkeypatch.delenv("VET_T_GLOBAL")
-    for k in ("entropy", "pairs", "srccount", "common"):
-        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    for k in ("pairs", "srccount", "common"):
+        assert np.array_equal(a[k], b[k]), k
+    np.testing.assert_allclose(b["entropy"], a["entropy"], rtol=1e-13, equal_nan=True)     # other workgroup size: other summation tree
     ent, pairs = vo.transition_series(mu, mv, 100, 200, [50, 200])
     assert np.array_equal(a["pairs"], pairs)
     np.testing.assert_allclose(a["entropy"], ent, rtol=1e-9, equal_nan=True)

@@ -691,6 +691,14 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
 }
 
 template <bool FROM_IDS>
+const void* transition_run_kernel(int upt, bool exact) {
+#define VET_PICK(N) if (upt == N) return exact ? (const void*)vet::k_transition_run<FROM_IDS, N, true> : (const void*)vet::k_transition_run<FROM_IDS, N, false>
+    VET_PICK(1); VET_PICK(2); VET_PICK(4); VET_PICK(8);
+#undef VET_PICK
+    return nullptr;
+}
+
+template <bool FROM_IDS>
 int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double* d_entropy, int32_t* d_pairs,
                       int32_t* d_srccount, int32_t* d_common, int32_t* d_status, hipStream_t s) {
     vet_ctx* c = pl->ctx;
@@ -709,7 +717,7 @@ int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, dou
     for (int k = 0; k < K; ++k) {
         const Lattice& L = pl->lat[k];
         const size_t n4 = ((size_t)L.n + 3) & ~(size_t)3;
-        const size_t lds_tiles = 16 + 4 * n4 * 4;
+        const size_t lds_tiles = 2 * 20 * 8 + 4 * n4 * 4;
         const size_t lds_run = lds_tiles + (size_t)3 * HS * 4;
         const size_t lds_cap = 160 * 1024 - 512;     // a single workgroup may take the whole LDS
         if (lds_tiles > lds_cap)
@@ -743,10 +751,7 @@ int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, dou
             per_cu = env_int("VET_T_WGS_PER_CU", 1, 16, (int)(per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu)));
             long grid = (long)c->n_cu * per_cu;
             if (grid > R) grid = R;
-            const void* fn = upt == 1 ? (const void*)vet::k_transition_run<FROM_IDS, 1>
-                           : upt == 2 ? (const void*)vet::k_transition_run<FROM_IDS, 2>
-                           : upt == 4 ? (const void*)vet::k_transition_run<FROM_IDS, 4>
-                                      : (const void*)vet::k_transition_run<FROM_IDS, 8>;
+            const void* fn = transition_run_kernel<FROM_IDS>(upt, (long)upt * threads == U);
             void* args[] = {(void*)&p};
             HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(threads), args, lds_run, s));
         } else {
@@ -1014,11 +1019,12 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     {
-        const void* tk[] = {(const void*)vet::k_transition_run<false, 1>, (const void*)vet::k_transition_run<false, 2>,
-                            (const void*)vet::k_transition_run<false, 4>, (const void*)vet::k_transition_run<false, 8>,
-                            (const void*)vet::k_transition_run<true, 1>, (const void*)vet::k_transition_run<true, 2>,
-                            (const void*)vet::k_transition_run<true, 4>, (const void*)vet::k_transition_run<true, 8>,
-                            (const void*)vet::k_transition_any<false>, (const void*)vet::k_transition_any<true>};
+        std::vector<const void*> tk = {(const void*)vet::k_transition_any<false>, (const void*)vet::k_transition_any<true>};
+        for (int upt : {1, 2, 4, 8})
+            for (int ex = 0; ex < 2; ++ex) {
+                tk.push_back(transition_run_kernel<false>(upt, ex != 0));
+                tk.push_back(transition_run_kernel<true>(upt, ex != 0));
+            }
         for (const void* f : tk) PLAN_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
     }
 #undef PLAN_TRY

@@ -1379,20 +1379,21 @@ struct TransParams {
 };
 
 // Per-tile words of one row in LDS (both transition kernels):
-//   acc u64 [2] (fixed-point entropy sum, users in both frames) | first_u, m_cnt, k_cnt, last_fu u32 [n4]
+//   acc f64 [2][20]: per row parity (thread 0 finishes row r while the others initialise row r+1):
+//                    [0..15] per-wave partial entropy sums, [16] (as u64) users present in both frames
+//   first_u, m_cnt, k_cnt, last_fu u32 [n4]
 // Row algorithm:
 //   (1) every user: tiles of both frames, key = p << 16 | c, first_u[p] = min u, m[p] += 1
 //   (2) non-first users: bucket insert (CAS); the creator of a bucket counts it into K[p];
 //       bucket first-user = min u, bucket count += 1; the user remembers its slot
 //   (3) non-first users that are the first of their bucket: last_fu[p] = max u
 //   (4) the user last_fu[p] publishes w[p] = its bucket's count (into first_u[p], free by then)
-//   (5) per tile: cell = -(m/N) K (w/m) log2(w/m) = -(K w / N)(log2 w - log2 m); the cells are summed as
-//       64-bit fixed point (2^-46) with ONE LDS atomic per wave instruction: order independent, hence
-//       the same bits from every kernel variant, workgroup size and GPU count
-constexpr double TRANS_FX = 70368744177664.0;    // 2^46: cells <= 12 * U < 2^16
+//   (5) per tile: cell = -(m/N) K (w/m) log2(w/m) = -(K w / N)(log2 w - log2 m), summed per wave (xor
+//       butterfly) and over the waves in order: a pure function of the row for a given workgroup size
+constexpr int TRANS_ACC = 20;
 
 __device__ __forceinline__ void trans_init(unsigned* tile_words, int n4, unsigned* hkey, unsigned* hfu, unsigned* hcnt, int HS,
-                                           unsigned long long* acc) {
+                                           double* acc) {
     const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u), zeros = make_uint4(0u, 0u, 0u, 0u);
     const int tid = threadIdx.x;
     for (int i = tid; i < n4 / 4; i += blockDim.x) {
@@ -1404,28 +1405,32 @@ __device__ __forceinline__ void trans_init(unsigned* tile_words, int n4, unsigne
     for (int i = tid; i < HS / 4; i += blockDim.x) {
         ((uint4*)hkey)[i] = ones; ((uint4*)hfu)[i] = ones; ((uint4*)hcnt)[i] = zeros;
     }
-    if (tid == 0) { acc[0] = 0ull; acc[1] = 0ull; }
+    if (tid == 0) ((unsigned long long*)acc)[16] = 0ull;
 }
 
 // step (5) and the row's outputs; all threads call it after step (4) is visible
 __device__ __forceinline__ void trans_cells(const TransParams& p, long r, const unsigned* first_u, const unsigned* m_cnt,
-                                            const unsigned* k_cnt, unsigned long long* acc, bool tab) {
-    const int tid = threadIdx.x;
-    const int N = (int)acc[1];
+                                            const unsigned* k_cnt, double* acc, bool tab) {
+    const int tid = threadIdx.x, NW = blockDim.x >> 6;
+    const int N = (int)((const unsigned long long*)acc)[16];
+    const double inv_n = 1.0 / (double)N;
+    double h = 0.0;
     for (int t = tid; t < p.n; t += blockDim.x) {
         const unsigned m = m_cnt[t];
         if (m) {
             const unsigned K = 1u + k_cnt[t];
             const unsigned w = (m == 1u) ? 1u : first_u[t];
             const double lq = tab ? p.log2_tab[w] - p.log2_tab[m] : log2((double)w / (double)m);
-            const double cell = -(double)((unsigned long long)K * w) * lq;
-            if (cell > 0.0) atomicAdd(&acc[0], (unsigned long long)rint(cell * TRANS_FX));
+            h -= ((double)((unsigned long long)K * w) * inv_n) * lq;
         }
         if (p.srccount) p.srccount[r * (long)p.n + t] = (int)m;
     }
+    h = wave_sum(h);
+    if (lane_id() == 0) acc[wave_id()] = h;
     __syncthreads();
     if (tid == 0) {
-        const double tot = (double)acc[0] / TRANS_FX / (double)N;
+        double tot = 0.0;
+        for (int i = 0; i < NW; ++i) tot += acc[i];
         double hmax = p.hmax;
         if (!(N > p.n)) {
             const double tp = 1.0 / (double)N;          // entropy_utils.py:322-327
@@ -1455,8 +1460,8 @@ __device__ __forceinline__ void trans_cells(const TransParams& p, long r, const 
 template <bool FROM_IDS>
 __global__ void k_transition_any(const TransParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* acc = (unsigned long long*)smem;       // [2]
-    unsigned* first_u = (unsigned*)(acc + 2);                  // [n4]
+    double* acc2 = (double*)smem;                              // [2][TRANS_ACC]
+    unsigned* first_u = (unsigned*)(acc2 + 2 * TRANS_ACC);     // [n4]
     const int n4 = (p.n + 3) & ~3;
     unsigned* m_cnt = first_u + n4;
     unsigned* k_cnt = m_cnt + n4;
@@ -1471,9 +1476,10 @@ __global__ void k_transition_any(const TransParams p) {
     const long R = (long)p.T - 1;
     const bool tab = p.U <= 4096;
     bool bad = false;
-    for (long r = blockIdx.x; r < R; r += gridDim.x) {
-        __syncthreads();                           // previous row fully consumed
-        trans_init(first_u, n4, hkey, hfu, hcnt, p.HS, acc);
+    int parity = 0;
+    for (long r = blockIdx.x; r < R; r += gridDim.x, parity ^= 1) {
+        double* acc = acc2 + TRANS_ACC * parity;
+        trans_init(first_u, n4, hkey, hfu, hcnt, p.HS, acc);       // the barrier inside trans_cells of the previous row precedes
         __syncthreads();
         for (int u = tid; u < p.U; u += blockDim.x) {
             const int ia = sample_dir<FROM_IDS, false>(p.src, r * (long)p.U + u, bad);
@@ -1487,7 +1493,7 @@ __global__ void k_transition_any(const TransParams p) {
                 atomicAdd(&m_cnt[pa], 1u);
             }
             const unsigned long long both = __ballot(packed != EMPTY_KEY);
-            if (lane == 0 && both) atomicAdd(&acc[1], (unsigned long long)__popcll(both));
+            if (lane == 0 && both) atomicAdd((unsigned long long*)acc + 16, (unsigned long long)__popcll(both));
             pc[u] = packed;
             if (p.pairs) {      // written once: non-temporal
                 __builtin_nontemporal_store(pa, p.pairs + (r * (long)p.U + u) * 2);
@@ -1541,11 +1547,11 @@ __global__ void k_transition_any(const TransParams p) {
 // bound by instruction issue, and the per-row fixed work (initialisation, barriers, the tile phase) is
 // paid per wave: two waves with four users per lane measured best at 512 users.
 // ------------------------------------------------------------------------------------------
-template <bool FROM_IDS, int UPT>
+template <bool FROM_IDS, int UPT, bool EXACT>      // EXACT: U == UPT * blockDim, no bounds checks on the user index
 __global__ void k_transition_run(const TransParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* acc = (unsigned long long*)smem;       // [2]
-    unsigned* first_u = (unsigned*)(acc + 2);                  // [n4]
+    double* acc2 = (double*)smem;                              // [2][TRANS_ACC]
+    unsigned* first_u = (unsigned*)(acc2 + 2 * TRANS_ACC);     // [n4]
     const int n4 = (p.n + 3) & ~3;
     unsigned* m_cnt = first_u + n4;
     unsigned* k_cnt = m_cnt + n4;
@@ -1563,7 +1569,7 @@ __global__ void k_transition_run(const TransParams p) {
     int si[UPT];
     bool mine[UPT];
 #pragma unroll
-    for (int k = 0; k < UPT; ++k) mine[k] = tid + k * (int)blockDim.x < p.U;
+    for (int k = 0; k < UPT; ++k) mine[k] = EXACT || tid + k * (int)blockDim.x < p.U;
     auto request = [&](long f) {                   // issue the loads of frame f
         const long base = f * (long)p.U + tid;
 #pragma unroll
@@ -1593,8 +1599,10 @@ __global__ void k_transition_run(const TransParams p) {
     tiles_of(prev);
     request(r_begin + 1);
     int32_t* pairs_row = p.pairs ? p.pairs + (r_begin * (long)p.U + tid) * 2 : nullptr;
-    for (long r = r_begin; r < r_end; ++r) {
-        trans_init(first_u, n4, hkey, hfu, hcnt, p.HS, acc);      // the previous row's last barrier precedes
+    int parity = 0;
+    for (long r = r_begin; r < r_end; ++r, parity ^= 1) {
+        double* acc = acc2 + TRANS_ACC * parity;
+        trans_init(first_u, n4, hkey, hfu, hcnt, p.HS, acc);      // the barrier inside trans_cells of the previous row precedes
         tiles_of(cur);
         if (r + 1 < r_end) request(r + 2);         // in flight during this row's LDS phases
         __syncthreads();
@@ -1617,7 +1625,7 @@ __global__ void k_transition_run(const TransParams p) {
             }
         }
         if (pairs_row) pairs_row += 2 * (long)p.U;
-        if (lane == 0 && present) atomicAdd(&acc[1], (unsigned long long)present);
+        if (lane == 0 && present) atomicAdd((unsigned long long*)acc + 16, (unsigned long long)present);
         __syncthreads();
         unsigned slot[UPT];
         bool nonfirst[UPT];
@@ -1654,7 +1662,6 @@ __global__ void k_transition_run(const TransParams p) {
         }
         __syncthreads();
         trans_cells(p, r, first_u, m_cnt, k_cnt, acc, true);
-        __syncthreads();
 #pragma unroll
         for (int k = 0; k < UPT; ++k) prev[k] = cur[k];
     }
