@@ -226,6 +226,16 @@ int vet_transition_entropy_host_resident(vet_plan *plan, const double *h_mu, con
 int vet_result_fetch(vet_result *result, int which, int64_t row0, int64_t n_rows, void *h_dst);
 int vet_result_free(vet_result *result);
 
+/* ---- tile boundary geometry of a Fibonacci tiling ---------------------------------------------
+ * get_fb_tile_boundaries (utilities/data_utils.py:58-189): for every tile the boundary edges (pairs of points on
+ * the unit sphere) in the order the reference appends them.  h_tiles [n*3] are the lattice Vectors as
+ * generate_fibonacci_lattice returns them; h_edges [n][max_edges][2][3] (NaN padded), h_count [n] edges per tile.
+ * VET_ERR_UNSUPPORTED when a tile has more than 32 neighbours within 1.7 x its nearest one or more than
+ * max_edges edges.  Synchronous.  The corner walk and the spherical-excess areas built on the edges
+ * (get_tile_corners :530-575, compute_spherical_polygon_area :657-678) stay on the host. */
+int vet_fb_tile_boundaries(vet_ctx *ctx, const double *h_tiles, int n_tiles, int max_edges,
+                           double *h_edges, int32_t *h_count);
+
 /* ---- host-side track loader (no GPU involved) -------------------------------------------
  * Replaces the per-file `pd.read_csv(filepath)` + column selection of process_viewport_data
  * (utilities/data_utils.py:305-316) for a whole directory: the files are parsed on n_threads host

@@ -14,7 +14,8 @@ Fixtures:
   G1 lattices, G2 quantiser tables, G3 exhaustive nearest-tile tables,
   G4 spatial analyzer runs (config 1), G5 transition analyzer runs,
   G6 ingest edge cases, G7 per-direction weight rows, G8 dense transition
-  frames (bucket quirk exercised), G9 operator-level edge cases, G10 naive lat/lon analyzer.
+  frames (bucket quirk exercised), G9 operator-level edge cases, G10 naive lat/lon analyzer,
+  G11 tile boundary / area geometry of the Fibonacci tiling.
 """
 
 from __future__ import annotations
@@ -510,6 +511,56 @@ def g10_naive(vt, synth):
     np.savez_compressed(OUT / "g10_naive.npz", **out)
 
 
+def g11_geometry(vt):
+    """Tile boundary / area geometry of the Fibonacci tiling: get_fb_tile_boundaries,
+    get_tile_corners, compute_spherical_polygon_area, compute_fb_tile_areas, utilities/data_utils.py:58-189,
+    530-575, 657-710.  Per tile: the boundary edges in the order the reference emits them ([E][2][3], NaN
+    padded), the corner walk of get_tile_corners, the tile area and the fraction of the sphere."""
+    from viewport_entropy_toolkit.utilities import data_utils as du
+    out = {}
+    for tc in (20, 50, 100, 33):
+        b = du.get_fb_tile_boundaries(tc)
+        n = len(b)
+        emax = max(len(v) for v in b.values())
+        edges = np.full((n, emax, 2, 3), np.nan)
+        count = np.zeros(n, dtype=np.int32)
+        for i, lst in b.items():
+            count[i] = len(lst)
+            for e, (p1, p2) in enumerate(lst):
+                edges[i, e, 0] = [p1.x, p1.y, p1.z]
+                edges[i, e, 1] = [p2.x, p2.y, p2.z]
+        cmax = 0
+        corners = {}
+        for i, lst in b.items():
+            corners[i] = vec_arr(du.get_tile_corners(lst))
+            cmax = max(cmax, len(corners[i]))
+        carr = np.full((n, cmax, 3), np.nan)
+        ccount = np.zeros(n, dtype=np.int32)
+        for i, c in corners.items():
+            carr[i, :len(c)] = c
+            ccount[i] = len(c)
+        areas, fractions = du.compute_fb_tile_areas(tc)
+        out[f"tc{tc}__edges"] = edges
+        out[f"tc{tc}__edge_count"] = count
+        out[f"tc{tc}__corners"] = carr
+        out[f"tc{tc}__corner_count"] = ccount
+        out[f"tc{tc}__areas"] = np.array([areas[i] for i in range(n)])
+        out[f"tc{tc}__fractions"] = np.array([fractions[i] for i in range(n)])
+        print("G11", tc, n, "edges", int(count.sum()), "area sum / 4pi", float(sum(areas.values()) / (4 * np.pi)), flush=True)
+    # the stand-alone helpers on a few explicit inputs
+    tri = [vt.Vector(1.0, 0.0, 0.0), vt.Vector(0.0, 1.0, 0.0), vt.Vector(0.0, 0.0, 1.0)]
+    out["octant_area"] = np.array(du.calculate_spherical_triangle_area(*tri))
+    rng = np.random.default_rng(11)
+    pts = rng.normal(size=(40, 3, 3))
+    pts /= np.linalg.norm(pts, axis=-1, keepdims=True)
+    out["tri_points"] = pts
+    out["tri_areas"] = np.array([du.calculate_spherical_triangle_area(*[vt.Vector(*p) for p in t]) for t in pts])
+    n1, n2 = rng.normal(size=(2, 30, 3))
+    out["gc_n1"], out["gc_n2"] = n1, n2
+    out["gc_p1"] = np.array([du.great_circle_intersection(a, b)[0] for a, b in zip(n1, n2)])
+    np.savez_compressed(OUT / "g11_geometry.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -540,6 +591,8 @@ def main():
         g8_dense_transition(vt, synth)
     if want("G10"):
         g10_naive(vt, synth)
+    if want("G11"):
+        g11_geometry(vt)
     if want("G4"):
         g4_spatial(vt, synth)
     if want("G5"):

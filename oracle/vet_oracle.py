@@ -389,3 +389,114 @@ def format_trajectories(tracks: List[Tuple[np.ndarray, np.ndarray, np.ndarray]])
     for f, u, ai, bi in cells:
         mu[f, u], mv[f, u] = ai, bi
     return np.array(times), mu, mv
+
+
+# --------------------------------------------------------------------------- #
+# tile boundary / area geometry of the Fibonacci tiling      #
+# --------------------------------------------------------------------------- #
+def _norm3(v: np.ndarray) -> np.ndarray:
+    return np.sqrt((v * v).sum(axis=-1))
+
+
+def _gc_point_near(n_a: np.ndarray, n_b: np.ndarray, centre: np.ndarray):
+    """data_utils.py:445-468 + 483-503: the two great circles with normals n_a, n_b meet in +-p,
+    p = normalise(cross(normalise(n_a), normalise(n_b))); the one whose chord to ``centre`` is shorter after
+    rounding to 4 decimals wins, ties go to -p.  Returns (point, rounded chord length)."""
+    p = np.cross(n_a / _norm3(n_a), n_b / _norm3(n_b))
+    p = p / _norm3(p)
+    l1 = np.round(_norm3(centre - p), 4)
+    l2 = np.round(_norm3(centre + p), 4)
+    return (p, l1) if l1 < l2 else (-p, l2)
+
+
+def fb_tile_boundaries(tile_count: int) -> List[List[Tuple[np.ndarray, np.ndarray]]]:
+    """data_utils.py:58-189 (get_fb_tile_boundaries): per tile the list of boundary edges (two points each)
+    in the order the reference appends them."""
+    if tile_count <= 0:
+        raise ValueError("Tile counts cannot be less than 1 for to visualize tiling!")
+    C = fibonacci_lattice(tile_count)
+    n = len(C)
+    result = []
+    for i in range(n):
+        seg = C[i] - C                                   # get_line_segment(c_i, c_j) for every j
+        length = _norm3(seg)
+        others = [j for j in range(n) if j != i]
+        order = sorted(others, key=lambda j: length[j])  # stable: ties keep index order
+        edges = []
+        if order:
+            limit = length[order[0]] * 1.7
+            near = []
+            for j in order:
+                if length[j] >= limit:
+                    break
+                near.append(j)
+            for a, j in enumerate(near):
+                hits = []
+                for b, k in enumerate(near):
+                    if b == a:
+                        continue
+                    pt, chord = _gc_point_near(seg[j], seg[k], C[i])
+                    hits.append((pt, chord, k))
+                if len(hits) < 2:
+                    continue
+                hits.sort(key=lambda h: h[1])
+                first, second = hits[0], hits[1]
+                _, corner_chord = _gc_point_near(seg[first[2]], seg[second[2]], C[i])
+                mid = (C[i] + C[j]) / 2
+                mid = mid / _norm3(mid)
+                if corner_chord > np.round(_norm3(C[i] - mid), 4):
+                    edges.append((first[0], second[0]))
+        result.append(edges)
+    return result
+
+
+def tile_corners(edges: Sequence[Tuple[np.ndarray, np.ndarray]]) -> np.ndarray:
+    """data_utils.py:530-575 (get_tile_corners): corner walk over the edges rounded to 4 decimals."""
+    key = lambda p: tuple((np.round(np.asarray(p, dtype=np.float64), 4) + 0.0).tolist())   # noqa: E731
+    start = [key(edges[0][0]), key(edges[0][1])]
+    walk = list(start)
+    seen = {start[0]: True, start[1]: True}
+    adj: Dict[tuple, list] = {}
+    for p1, p2 in edges:
+        k1, k2 = key(p1), key(p2)
+        adj.setdefault(k1, []).append(k2)
+        adj.setdefault(k2, []).append(k1)
+        seen.setdefault(k1, False)
+        seen.setdefault(k2, False)
+    cur = walk[1]
+    while not seen[adj[cur][0]] or not seen[adj[cur][1]]:
+        cur = adj[cur][0] if not seen[adj[cur][0]] else adj[cur][1]
+        walk.append(cur)
+        seen[cur] = True
+    return np.array(walk, dtype=np.float64)
+
+
+def spherical_triangle_area(p1, p2, p3) -> float:
+    """data_utils.py:600-655: spherical excess of the triangle of the three normalised points."""
+    v = [np.asarray(p, dtype=np.float64) / _norm3(np.asarray(p, dtype=np.float64)) for p in (p1, p2, p3)]
+
+    def angle(a, b, c):
+        t1 = b - np.dot(b, a) * a
+        t2 = c - np.dot(c, a) * a
+        t1 = t1 / _norm3(t1)
+        t2 = t2 / _norm3(t2)
+        return np.arccos(np.clip(np.dot(t1, t2), -1.0, 1.0))
+
+    return float(angle(v[0], v[1], v[2]) + angle(v[1], v[2], v[0]) + angle(v[2], v[0], v[1]) - np.pi)
+
+
+def polygon_area(edges) -> float:
+    """data_utils.py:657-678: fan triangulation from the first corner of the corner walk."""
+    c = tile_corners(edges)
+    if len(c) < 3:
+        raise ValueError("At least 3 boundary points are needed for a polygon.")
+    total = 0.0
+    for i in range(1, len(c) - 1):
+        total += spherical_triangle_area(c[0], c[i], c[i + 1])
+    return total
+
+
+def fb_tile_areas(tile_count: int):
+    """data_utils.py:680-710: (areas[n], fractions of the sphere[n])."""
+    areas = np.array([polygon_area(e) for e in fb_tile_boundaries(tile_count)])
+    return areas, areas / (4 * np.pi)

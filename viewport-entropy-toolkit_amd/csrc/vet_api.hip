@@ -40,6 +40,12 @@ int fail(int code, const char* fmt, ...) {
                         __FILE__, __LINE__);                                                 \
     } while (0)
 
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t b) { return hipMalloc(&p, b ? b : 8); }
+};
+
 enum { KID_GRID = 0, KID_NEAREST = 1, KID_SPATIAL = 2, KID_TRANSITION = 3, KID_FINALIZE = 4, KID_WTAB = 5, KID_COUNT = 6 };
 const char* const kKernelNames[KID_COUNT] = {"k_grid_dirs", "k_nearest_lut", "k_spatial", "k_transition",
                                              "k_finalize", "k_wtab"};
@@ -1065,6 +1071,34 @@ int vet_plan_table_stride(const vet_plan* pl, int k) {
     return pl->lat[k].stride;
 }
 
+// get_fb_tile_boundaries (utilities/data_utils.py:58-189) for one lattice; synchronous, host buffers
+int vet_fb_tile_boundaries(vet_ctx* c, const double* h_tiles, int n, int max_edges, double* h_edges, int32_t* h_count) {
+    if (!c || !h_tiles || !h_edges || !h_count) return fail(VET_ERR_INVALID, "ctx, tiles or an output is NULL");
+    if (n <= 0 || max_edges <= 0) return fail(VET_ERR_INVALID, "need n > 0 tiles and max_edges > 0");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t eb = (size_t)n * max_edges * 6 * sizeof(double);
+    DevBuf tiles, edges, count, err;
+    HIP_TRY(tiles.alloc((size_t)n * 24));
+    HIP_TRY(edges.alloc(eb));
+    HIP_TRY(count.alloc((size_t)n * 4));
+    HIP_TRY(err.alloc(4));
+    HIP_TRY(hipMemcpyAsync(tiles.p, h_tiles, (size_t)n * 24, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(edges.p, 0xFF, eb, s));            // NaN padding
+    HIP_TRY(hipMemsetAsync(err.p, 0, 4, s));
+    hipLaunchKernelGGL(vet::k_fb_boundaries, dim3((n + 63) / 64), dim3(64), 0, s, (const double*)tiles.p, n, max_edges,
+                       (double*)edges.p, (int32_t*)count.p, (int32_t*)err.p);
+    HIP_TRY(hipGetLastError());
+    int32_t bad = 0;
+    HIP_TRY(hipMemcpyAsync(h_edges, edges.p, eb, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h_count, count.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&bad, err.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (bad) return fail(VET_ERR_UNSUPPORTED, "%d tile(s) with more than %d neighbours or more than %d edges", bad,
+                         vet::FB_MAX_NEIGHBOURS, max_edges);
+    return VET_OK;
+}
+
 int vet_plan_last_formulation(const vet_plan* pl, int k) {
     if (!pl || k < 0 || k >= (int)pl->lat.size()) return -1;
     return pl->lat[k].last_form;
@@ -1216,13 +1250,6 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
 
 // ------------------------------------------------------------------------------------------------
 // host-buffer variants: stage through the context's grow-only device buffers (synchronous)
-namespace {
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t b) { return hipMalloc(&p, b ? b : 8); }
-};
-}  // namespace
 
 // slot-indexed staging buffer of at least `bytes` bytes (kept by the context between calls)
 static int pooled(vet_ctx* c, int slot, size_t bytes, void** out) {

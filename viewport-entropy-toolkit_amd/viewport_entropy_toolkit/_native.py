@@ -104,6 +104,7 @@ SIGNATURES = {
     "vet_transition_entropy_host_resident": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, C.POINTER(_P)]),
     "vet_result_fetch": (_I, [_P, _I, _I64, _I64, _P]),
     "vet_result_free": (_I, [_P]),
+    "vet_fb_tile_boundaries": (_I, [_P, _P, _I, _I, _P, _P]),
     "vet_csv_read_tracks": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(Track), _I]),
     "vet_csv_free_tracks": (None, [_I, C.POINTER(Track)]),
 }
@@ -214,6 +215,15 @@ class Engine:
 
     def synchronize(self):
         _check(self.lib, self.lib.vet_synchronize(self.handle))
+
+    def fb_tile_boundaries(self, tiles: np.ndarray, max_edges: int = 16):
+        """k_fb_boundaries: (edges [n, max_edges, 2, 3] NaN padded, count [n]) for lattice Vectors ``tiles`` [n, 3]."""
+        tiles = np.ascontiguousarray(tiles, dtype=np.float64).reshape(-1, 3)
+        n = len(tiles)
+        edges = np.empty((n, max_edges, 2, 3), dtype=np.float64)
+        count = np.empty(n, dtype=np.int32)
+        _check(self.lib, self.lib.vet_fb_tile_boundaries(self.handle, _ptr(tiles), n, max_edges, _ptr(edges), _ptr(count)))
+        return edges, count
 
     # --- profiling -------------------------------------------------------
     def profile_enable(self, on: bool = True):

@@ -9,7 +9,11 @@ from . import data_utils as _data, entropy_utils as _entropy, visualization_util
 
 _PUBLIC = {
     _data: ("generate_fibonacci_lattice", "normalize_to_pixel", "pixel_to_spherical", "process_viewport_data",
-            "format_trajectory_data", "validate_video_dimensions"),
+            "format_trajectory_data", "validate_video_dimensions", "get_fb_tile_boundaries", "get_lat_lon_tiles",
+            "normalize", "find_perpendicular_on_tangent_plane", "great_circle_intersection", "get_line_segment",
+            "find_nearest_point", "spherical_interpolation", "get_tile_corners", "triangulate_spherical_polygon",
+            "angle_at_vertex", "calculate_spherical_triangle_area", "compute_spherical_polygon_area",
+            "compute_fb_tile_areas", "compute_lat_lon_tile_areas"),
     _entropy: ("EntropyConfig", "find_nearest_tile", "calculate_tile_weights", "compute_spatial_entropy",
                "compute_transition_entropy", "calculate_naive_tile_weights", "find_naive_tile_index",
                "compute_naive_spatial_entropy"),

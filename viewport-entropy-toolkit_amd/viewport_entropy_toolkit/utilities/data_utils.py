@@ -1,6 +1,6 @@
 """Lattice generation and ingest helpers with the reference's names and semantics
-(utilities/data_utils.py:25-56, 227-410).  The tile-boundary / spherical-area geometry of
-the reference's 3-D visualisation is not part of this engine.
+(utilities/data_utils.py:25-56, 227-410).  The tile-boundary / spherical-area geometry of the same reference
+module (:58-225, 412-741) lives in ``geometry.py`` and is re-exported here under the reference's names.
 """
 
 from __future__ import annotations
@@ -13,6 +13,11 @@ import pandas as pd
 
 from ..data_types import Point, RadialPoint, Vector, ValidationError
 from .. import _ingest, _quantiser
+from .geometry import (angle_at_vertex, calculate_spherical_triangle_area, compute_fb_tile_areas,  # noqa: F401
+                       compute_lat_lon_tile_areas, compute_spherical_polygon_area, find_nearest_point,
+                       find_perpendicular_on_tangent_plane, get_fb_tile_boundaries, get_lat_lon_tiles,
+                       get_line_segment, get_tile_corners, great_circle_intersection, normalize,
+                       spherical_interpolation, triangulate_spherical_polygon)
 
 
 def generate_fibonacci_lattice(num_points: int) -> List[Vector]:
