@@ -508,7 +508,7 @@ int choose_formulation(vet_plan* pl, int k, bool want_table, int U, hipStream_t 
 // one launch of the table kernel over lattices lat_idx[0..K) of the plan (single video or a batch)
 template <bool FROM_IDS>
 int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& src, int U, int T,
-               const vet::VideoDesc* d_videos, int n_videos, int blocks_batch, size_t lds_batch,
+               const vet::VideoDesc* d_videos, int n_videos, int blocks_batch, size_t lds_batch, int batch_max_users,
                double* d_entropy, int32_t* d_assign, double* d_weights, int32_t* d_present, int32_t* d_status,
                hipStream_t s, bool* launched) {
     vet_ctx* c = pl->ctx;
@@ -533,8 +533,11 @@ int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& sr
     }
     q.entropy = d_entropy; q.assign = d_assign; q.weights = d_weights; q.present = d_present;
     q.status = d_status;
-    q.stage = env_int("VET_LUT_STAGE", 0, 9, 0);
-    const bool dedup = (uint64_t)pl->n_dirs <= vet::DEDUP_MAX_DIRS && pl->d_dirrec && !getenv("VET_NO_DEDUP");
+    // the per-frame set of distinct rows pays for itself from ~128 users per frame on (measured: config 2, 64
+    // users, 0.0332 ms without vs 0.0366 ms with; config 4, 256 users, equal; config 3, 1024 users, 1.60 -> 1.53 ms)
+    const int dedup_users = env_int("VET_DEDUP_MIN_USERS", 1, 1 << 20, 128);
+    const bool dedup = (uint64_t)pl->n_dirs <= vet::DEDUP_MAX_DIRS && pl->d_dirrec && !getenv("VET_NO_DEDUP") &&
+                       (d_videos ? batch_max_users : U) >= dedup_users;
     int blocks = blocks_batch, threads = 256;
     size_t lds = lds_batch;
     bool occ8 = true;
@@ -601,7 +604,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         int idx[vet::MAX_LATTICES];
         for (int k = 0; k < K; ++k) idx[k] = k;
         bool launched = false;
-        int rc = launch_lut<FROM_IDS>(pl, idx, K, src, U, T, nullptr, 0, 0, 0, d_entropy, d_assign, d_weights, d_present,
+        int rc = launch_lut<FROM_IDS>(pl, idx, K, src, U, T, nullptr, 0, 0, 0, 0, d_entropy, d_assign, d_weights, d_present,
                                       d_status, s, &launched);
         if (launched) for (int k = 0; k < K; ++k) pl->lat[k].last_form = F_TABLE;
         if (rc || launched) return rc;
@@ -616,7 +619,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         const Lattice& L = pl->lat[k];
         if (form[k] == F_TABLE) {
             bool launched = false;
-            int rc = launch_lut<FROM_IDS>(pl, &k, 1, src, U, T, nullptr, 0, 0, 0, ent_k + (size_t)k * T,
+            int rc = launch_lut<FROM_IDS>(pl, &k, 1, src, U, T, nullptr, 0, 0, 0, 0, ent_k + (size_t)k * T,
                                           k == 0 ? d_assign : nullptr, k == 0 ? d_weights : nullptr,
                                           k == 0 ? d_present : nullptr, k == 0 ? d_status : nullptr, s, &launched);
             if (rc) return rc;
@@ -1211,7 +1214,8 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
     std::vector<vet::VideoDesc>& desc = c->batch_desc;
     size_t lds_max = 0;
     if (table) {
-        const bool dedup = (uint64_t)pl->n_dirs <= vet::DEDUP_MAX_DIRS && pl->d_dirrec && !getenv("VET_NO_DEDUP");
+        const bool dedup = (uint64_t)pl->n_dirs <= vet::DEDUP_MAX_DIRS && pl->d_dirrec && !getenv("VET_NO_DEDUP") &&
+                           max_users >= env_int("VET_DEDUP_MIN_USERS", 1, 1 << 20, 128);
         desc.resize(n_videos);
         int block = 0;
         for (int v = 0; v < n_videos && table; ++v) {
@@ -1235,7 +1239,7 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
             const vet::SampleSrc src{nullptr, nullptr, nullptr, pl->W, pl->H, (long)pl->n_dirs};
             bool launched = false;
             for (int k = 0; k < K; ++k) pl->lat[k].last_form = F_TABLE;
-            return launch_lut<false>(pl, idx, K, src, 0, 0, (const vet::VideoDesc*)d_desc, n_videos, block, lds_max, nullptr,
+            return launch_lut<false>(pl, idx, K, src, 0, 0, (const vet::VideoDesc*)d_desc, n_videos, block, lds_max, max_users, nullptr,
                                      nullptr, nullptr, nullptr, d_status, s, &launched);
         }
     }

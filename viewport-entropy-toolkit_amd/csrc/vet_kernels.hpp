@@ -819,7 +819,6 @@ struct LutParams {
     int32_t* present;
     int32_t* status;
     int FPW, UC;
-    int stage;                    // diagnostics: leave after stage N (0 = run everything)
 };
 
 // hash slots per frame: power of two >= 2 * UC, at least one wave's worth
@@ -846,7 +845,6 @@ __host__ __device__ __forceinline__ size_t lut_lds_bytes(int U, int UC, int FPW,
 template <bool FROM_IDS, int UN, bool IL, bool OCC8, bool DEDUP>
 __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (p.stage == 9) return;
     // the video this workgroup works on: the launch's only one, or one of a batch
     SampleSrc src = p.src;
     int U = p.U, T = p.T, FPW = p.FPW, UC = p.UC;
@@ -893,7 +891,6 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
         if (DEDUP)
             for (int i = tid; i < FPW * HS; i += blockDim.x) hash[i] = EMPTY_KEY;
         __syncthreads();
-        if (p.stage == 8) return;
         // SPT samples per thread and round: all sample loads first, then the table gathers, then the LDS set
         // inserts — three waves of independent requests instead of SPT dependent chains
         constexpr int SPT = 4;
@@ -938,6 +935,11 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
                     if (DEDUP) {
                         const uint2 rec = p.dirrec[id[k]];
                         row[k] = (rec.x & ROW_MASK) | ((rec.x >> 31) << ROW_BITS);
+                        near[k] = (int)(((rec.x >> ROW_BITS) & 0xFFFu) | ((rec.y >> 21) << 12));
+                        m0[k] = rec.y & 0x1FFFFFu;
+                    } else if (p.dirrec) {                      // small frames: no set, but the fused record
+                        const uint2 rec = p.dirrec[id[k]];
+                        row[k] = (rec.x & ROW_MASK) | (rec.x & 0x80000000u);
                         near[k] = (int)(((rec.x >> ROW_BITS) & 0xFFFu) | ((rec.y >> 21) << 12));
                         m0[k] = rec.y & 0x1FFFFFu;
                     } else {
@@ -989,19 +991,18 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
                     if (won) {
                         const size_t pos = (size_t)fl0 * UC + base + below(mw);
                         rows[pos] = DEDUP ? h : row[k];
-                        if (DEDUP) meta[pos] = m0[k];
+                        meta[pos] = m0[k];
                     }
                 } else {
                     if (valid) atomicAdd(&cnt_frame[fl], 1);
                     if (won) {
                         const size_t pos = (size_t)fl * UC + atomicAdd(&cnt_chunk[fl], 1);
                         rows[pos] = DEDUP ? h : row[k];
-                        if (DEDUP) meta[pos] = m0[k];
+                        meta[pos] = m0[k];
                     }
                 }
             }
         }
-        if (p.stage == 1) return;
         __syncthreads();
         if (DEDUP) {
             // slot numbers -> slot words (row << 12 | multiplicity)
@@ -1009,7 +1010,6 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
                 const int fl = i / UC, j = i - fl * UC;
                 if (j < cnt_chunk[fl]) rows[i] = hash[(size_t)fl * HS + rows[i]];
             }
-            if (p.stage == 2) return;
             if (overlay) {
                 __syncthreads();
                 for (int i = tid; i < FPW * p.n_sum; i += blockDim.x) hist[i] = 0ull;
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
             // meta words (length, shift) of this lattice for every staged row: one parallel gather, so the
             // walk below has no dependent global load in front of its row loads
             if (k) __syncthreads();
-            if (!(DEDUP && k == 0 && p.rec_meta))
+            if (!(k == 0 && p.rec_meta && (DEDUP || p.dirrec)))
                 for (int i = tid; i < nf * UC; i += blockDim.x) {
                     const int fl = i / UC, j = i - fl * UC;
                     if (j < cnt_chunk[fl]) meta[i] = L.tab_meta[DEDUP ? (rows[i] >> 12) & ROW_MASK : rows[i] & 0x7FFFFFFFu];
@@ -1039,7 +1039,6 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
             hoff += L.n;
         }
     }
-    if (p.stage == 3) return;
     __syncthreads();
     // entropy (entropy_utils.py:194-211, weighted: normaliser log2 n); wave w takes frames w, w+NW, ...
     const double inv_unit = 1.0 / (4294967296.0 * (double)(1u << TAB_X));
