@@ -1614,7 +1614,7 @@ __global__ void k_transition_run(const TransParams p) {
             const bool both = prev[k] >= 0 && cur[k] >= 0;      // present in both frames (entropy_utils.py:259-261)
             if (both) {
                 key[k] = ((unsigned)prev[k] << 16) | (unsigned)cur[k];
-                atomicMin(&first_u[prev[k]], u);
+                if (first_u[prev[k]] > u) atomicMin(&first_u[prev[k]], u);      // later users of a crowded tile skip the atomic
                 atomicAdd(&m_cnt[prev[k]], 1u);
             }
             present += (int)__popcll(__ballot(both));
@@ -1641,7 +1641,7 @@ __global__ void k_transition_run(const TransParams p) {
                     if (was == key[k]) break;
                     h = (h + 1) & (unsigned)(p.HS - 1);
                 }
-                atomicMin(&hfu[h], u);
+                if (hfu[h] > u) atomicMin(&hfu[h], u);
                 atomicAdd(&hcnt[h], 1u);
                 slot[k] = h;
             }
