@@ -20,11 +20,12 @@ class _RowView(Mapping):
     """Base of the per-frame views: holds references only; everything else is computed on access
     (a 30 000-frame result builds 60 000 of these, so construction must stay trivial)."""
 
-    __slots__ = ("_keys", "_row")
+    __slots__ = ("_keys", "_row", "_dict")
 
     def __init__(self, keys, row):
         self._keys = keys
         self._row = row
+        self._dict = None
 
     def _mask(self):
         raise NotImplementedError
@@ -36,16 +37,18 @@ class _RowView(Mapping):
         return ((self._keys[int(i)], self._value(i)) for i in np.nonzero(self._mask())[0])
 
     def _materialise(self) -> dict:
-        return dict(self._items())
+        if self._dict is None:           # built once: dict(view) asks for every key in turn
+            self._dict = dict(self._items())
+        return self._dict
 
     def __getitem__(self, key):
         return self._materialise()[key]
 
     def __iter__(self):
-        return (k for k, _ in self._items())
+        return iter(self._materialise())
 
     def __len__(self):
-        return int(np.count_nonzero(self._mask()))
+        return int(np.count_nonzero(self._mask())) if self._dict is None else len(self._dict)
 
     def __repr__(self):
         return repr(self._materialise())
@@ -59,6 +62,7 @@ class TileWeights(_RowView):
     def __init__(self, tiles: Sequence, row: np.ndarray, as_int: bool = False):
         self._keys = tiles
         self._row = row
+        self._dict = None
         self._as_int = as_int
 
     def _mask(self):
