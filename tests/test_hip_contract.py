@@ -83,7 +83,7 @@ def test_single_and_two_user_frames_over_all_directions(native, engine, tcs, fov
     plan.close()
 
 
-@pytest.mark.parametrize("tcs", [[1], [2], [3], [1, 3], [3, 50]])
+@pytest.mark.parametrize("tcs", [[1], [2], [3], [1, 3], [3, 50], [50, 3]])
 @pytest.mark.parametrize("policy", [1, -1, 0])
 @pytest.mark.parametrize("fov,power", [(120.0, 2.0), (30.0, 0.5), (360.0, 1.0)])
 def test_degenerate_lattices(native, engine, tcs, policy, fov, power):
