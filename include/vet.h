@@ -125,11 +125,14 @@ int64_t vet_plan_n_dirs(const vet_plan *plan);
  *              frame (memory bound); 32-bit block-floating-point weights, 64-bit integer histograms
  *   1 sweep    every sample sweeps every tile (FP64 VALU bound); 2^-52 fixed-point integer histograms
  *   2 precise  the sweep with the exact weights in FP64 histograms, in the reference's summation order
- * The integer formulations are order independent (bit-identical run to run, under any user
+ *   3 ftable   the table with FP32 weights (2^-24 relative each, scaled by their row's exponent) in FP64
+ *              histograms: |dH|/H <= 1.2e-7 for every frame whatever the weights' dynamic range
+ * The integer formulations (0, 1) are order independent (bit-identical run to run, under any user
  * permutation, frame split or GPU count).  They are only used where a bound computed from the plan's
  * own rows proves their deviation from exact arithmetic <= 1e-7 relative for EVERY possible frame
  * (k_row_stats; the contract is 1e-6); plans outside that — FoV cones narrower than the lattice
- * spacing, large power factors — run `precise`.
+ * spacing, large power factors — run `ftable` (calls large enough for a table) or `precise`; those two
+ * sum in FP64 and are reproducible to ~1e-15, not bit for bit (`ftable`: LDS atomics in arrival order).
  * Which formulation a call uses is a pure function of the plan and the call's shape, never of the
  * plan's history: policy 0 = table iff the call (or batch) holds >= 8 samples per direction of the
  * plan's direction table, +1 = table whenever it is inside the contract and fits, -1 = never table.

@@ -73,7 +73,7 @@ def test_single_and_two_user_frames_over_all_directions(native, engine, tcs, fov
         form = plan.last_formulation(0)
         # an integer formulation only where the plan's own bound puts it inside the contract
         table_asked = policy > 0 or (policy == 0 and mu.size >= 8 * (W + 1) * (H + 1))
-        want = "table" if (table_asked and tab_bound <= 1e-7) else ("sweep" if sweep_bound <= 1e-7 else "precise")
+        want = ("table" if tab_bound <= 1e-7 else "ftable") if table_asked else ("sweep" if sweep_bound <= 1e-7 else "precise")
         assert form == want, (name, form, tab_bound, sweep_bound)
         ent, assign = oracle_for(tcs, fov, power, name, mu, mv)
         assert np.array_equal(res["assign"], assign), name
@@ -107,7 +107,9 @@ def test_degenerate_lattices(native, engine, tcs, policy, fov, power):
     assert np.array_equal(np.isnan(res["entropy"]), np.isnan(ent)), (res["entropy"][:10], ent[:10])
     ok = ~np.isnan(ent)
     np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=1e-6, atol=ATOL)
-    np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=2.0 ** -33 * U)
+    # FP32 table weights: 2^-24 relative each; integer tables: 2^-33 absolute
+    np.testing.assert_allclose(res["weights"], weights, rtol=1e-7 if plan.last_formulation(0) == "ftable" else 1e-9,
+                               atol=2.0 ** -33 * U)
     plan.close()
 
 
@@ -161,4 +163,7 @@ def test_error_bounds_of_the_baseline_plans(native, engine):
             assert tab == np.inf and sweep == np.inf          # every row has at most one tile in its FoV
         else:
             assert tab > 1e-7
+        plan.set_table_policy(1)                              # ... so the table such a plan builds holds FP32 weights
+        plan.spatial(mu=np.full((2, 3), 0.4), mv=np.full((2, 3), 0.6))
+        assert plan.last_formulation(0) == "ftable"
         plan.close()

@@ -67,9 +67,11 @@ def test_hip_matches_oracle(native, engine, pr):
                                                      power_factor=pr["power"], use_weight_distribution=weighted,
                                                      want_weights=True)
             assert np.array_equal(res["assign"], assign)
-            np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=2.0 ** -32 * pr["U"] + 1e-12)
+            np.testing.assert_allclose(res["weights"], weights, rtol=1e-7 if plan.last_formulation(0) == "ftable" else 1e-9,
+                                       atol=2.0 ** -32 * pr["U"] + 1e-12)
             ok = np.isfinite(ent)
             assert np.array_equal(np.isnan(res["entropy"]), np.isnan(ent))
-            np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=1e-8, atol=1e-15)
+            fp = any(plan.last_formulation(k) == "ftable" for k in range(len(tcs)))
+            np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=2e-7 if fp else 1e-8, atol=1e-15)
     finally:
         plan.close()

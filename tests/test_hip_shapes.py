@@ -165,10 +165,12 @@ def test_extreme_entropy_configs(native, engine, fov, power, policy):
                                              want_weights=True)
     assert np.array_equal(res["assign"], assign)
     # the table stores 32-bit mantissas below the row's largest weight: at most 2^-32 absolute per weight
-    np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=2.0 ** -32 * 60 + 1e-12)
+    np.testing.assert_allclose(res["weights"], weights, rtol=1e-7 if plan.last_formulation(0) == "ftable" else 1e-9,
+                               atol=2.0 ** -32 * 60 + 1e-12)
     assert np.array_equal(np.isnan(res["entropy"]), np.isnan(ent))
     ok = np.isfinite(ent)
-    np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=1e-8, atol=1e-15)
+    fp = "ftable" in (plan.last_formulation(0), plan.last_formulation(1))       # FP32 table weights: |dH|/H <= 1.2e-7
+    np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=2e-7 if fp else 1e-8, atol=1e-15)
     plan.close()
 
 

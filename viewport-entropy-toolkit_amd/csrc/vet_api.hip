@@ -94,6 +94,8 @@ struct Lattice {
     uint16_t* d_tab_i = nullptr;   // [n_dirs+1][stride]
     uint32_t* d_tab_meta = nullptr;// [n_dirs+1] entries in use | row shift << 16
     uint8_t* d_row_s = nullptr;    // [n_dirs+1] row shift (k_row_stats)
+    uint16_t* d_row_e = nullptr;   // [n_dirs+1] unclamped row exponent (FP table)
+    bool fp_table = false;         // the table holds FP32 weights (plans whose integer bound is outside the contract)
     // k_row_stats: worst-case relative entropy error of integer histograms over every possible frame
     bool stats_done = false;
     double crit_tab = 0.0;         // table formulation (step 2^(e_row - 33) per entry)
@@ -255,8 +257,14 @@ const void* spatial_w_kernel(int wmode, int R, bool precise = false) {
 }
 
 template <bool FROM_IDS>
-const void* lut_kernel(bool il, bool occ8, bool dedup) {
-#define VET_PICK(I, O, D) if (il == I && occ8 == O && dedup == D) return (const void*)vet::k_spatial_lut<FROM_IDS, 2, I, O, D>
+const void* lut_kernel(bool il, bool occ8, bool dedup, bool fpt = false) {
+    if (fpt) {      // FP table: 7 workgroups per CU (FP64 scale registers)
+#define VET_PICKF(I, D) if (il == I && dedup == D) return (const void*)vet::k_spatial_lut<FROM_IDS, 2, I, false, D, true>
+        VET_PICKF(false, false); VET_PICKF(true, false); VET_PICKF(false, true); VET_PICKF(true, true);
+#undef VET_PICKF
+        return nullptr;
+    }
+#define VET_PICK(I, O, D) if (il == I && occ8 == O && dedup == D) return (const void*)vet::k_spatial_lut<FROM_IDS, 2, I, O, D, false>
     VET_PICK(false, false, false); VET_PICK(false, true, false); VET_PICK(true, false, false); VET_PICK(true, true, false);
     VET_PICK(false, false, true); VET_PICK(false, true, true); VET_PICK(true, false, true); VET_PICK(true, true, true);
 #undef VET_PICK
@@ -333,7 +341,8 @@ int ensure_stats(vet_plan* pl, int k, hipStream_t s) {
     vet_ctx* c = pl->ctx;
     unsigned long long* d_crit = nullptr;
     HIP_TRY(hipMalloc((void**)&d_crit, 16));
-    if (!L.d_row_s && hipMalloc((void**)&L.d_row_s, (size_t)pl->n_dirs + 1) != hipSuccess) {
+    if ((!L.d_row_s && hipMalloc((void**)&L.d_row_s, (size_t)pl->n_dirs + 1) != hipSuccess) ||
+        (!L.d_row_e && hipMalloc((void**)&L.d_row_e, ((size_t)pl->n_dirs + 1) * 2) != hipSuccess)) {
         (void)hipFree(d_crit);
         return fail(VET_ERR_DEVICE, "hipMalloc of the row shift table failed");
     }
@@ -343,7 +352,7 @@ int ensure_stats(vet_plan* pl, int k, hipStream_t s) {
     p.tiles = L.d_tiles; p.n = L.n;
     p.cos_cull = pl->cos_cull;
     p.wc.max_ang = pl->max_ang; p.wc.inv_max = 1.0 / pl->max_ang; p.wc.power = pl->power; p.wc.shift = 0;
-    p.row_s = L.d_row_s; p.crit = d_crit;
+    p.row_s = L.d_row_s; p.row_e = L.d_row_e; p.crit = d_crit;
     const int blocks = grid_for((long)pl->n_dirs * vet::WAVE, 256, c->n_cu * 2);
     {
         ProfScope ps(c, s, KID_WTAB);
@@ -379,7 +388,10 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     p.tiles = L.d_tiles; p.n = L.n;
     p.cos_cull = pl->cos_cull;
     p.wc.max_ang = pl->max_ang; p.wc.inv_max = 1.0 / pl->max_ang; p.wc.power = pl->power; p.wc.shift = 0;
-    p.stride = 0; p.w = nullptr; p.idx = nullptr; p.meta = nullptr; p.row_s = L.d_row_s; p.maxcount = d_max; p.gs_log2 = -1;
+    // integer mantissas where their error bound is inside the contract, FP32 weights otherwise
+    L.fp_table = !(L.crit_tab <= kContractMargin);
+    p.stride = 0; p.w = nullptr; p.idx = nullptr; p.meta = nullptr; p.row_s = L.d_row_s; p.row_e = L.d_row_e; p.fp = L.fp_table ? 1 : 0;
+    p.maxcount = d_max; p.gs_log2 = -1;
     const int blocks = grid_for((long)pl->n_dirs * vet::WAVE, 256, c->n_cu * 2);
     {
         ProfScope ps(c, s, KID_WTAB);
@@ -469,7 +481,7 @@ bool any_binned(const vet_plan* pl) {
 //            cheaper than a swept one), if the table fits and its error bound is inside the contract;
 //   sweep    integer (2^-52) histogram, if its error bound is inside the contract;
 //   precise  FP64 histogram and exact weights otherwise.
-enum { F_TABLE = 0, F_SWEEP = 1, F_PRECISE = 2 };
+enum { F_TABLE = 0, F_SWEEP = 1, F_PRECISE = 2, F_FTABLE = 3 };
 
 bool table_requested(const vet_plan* pl, long samples, int U) {
     if (!pl->weighted || pl->table_policy < 0 || any_binned(pl) || U >= 65536) return false;
@@ -496,10 +508,10 @@ int choose_formulation(vet_plan* pl, int k, bool want_table, int U, hipStream_t 
     Lattice& L = pl->lat[k];
     int rc = ensure_stats(pl, k, s);
     if (rc) return rc;
-    if (want_table && L.crit_tab <= kContractMargin) {
+    if (want_table) {
         rc = ensure_wtab(pl, k, s);
         if (rc) return rc;
-        if (L.stride > 0) { *out = F_TABLE; return VET_OK; }
+        if (L.stride > 0) { *out = L.fp_table ? F_FTABLE : F_TABLE; return VET_OK; }
     }
     *out = sweep_formulation(pl, L, U);
     return VET_OK;
@@ -522,6 +534,7 @@ int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& sr
     q.rec_meta = lat_idx[0] == 0 ? 1 : 0;
     q.K = K; q.n_sum = 0;
     bool il = false;
+    const bool fpt = pl->lat[lat_idx[0]].fp_table;       // the caller passes lattices of one kind
     for (int k = 0; k < K; ++k) {
         const Lattice& L = pl->lat[lat_idx[k]];
         q.lat[k].tab_w = L.d_tab_w; q.lat[k].tab_i = L.d_tab_i; q.lat[k].tab_meta = L.d_tab_meta;
@@ -561,7 +574,7 @@ int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& sr
     ProfScope ps(c, s, KID_SPATIAL);
     void* args[] = {(void*)&q};
     // 2 rows in flight per lane group measured best (4 and 8 were tried, profiles/r01/v3_*)
-    HIP_TRY(hipLaunchKernel(lut_kernel<FROM_IDS>(il, occ8, dedup), dim3((unsigned)blocks), dim3(threads), args, lds, s));
+    HIP_TRY(hipLaunchKernel(lut_kernel<FROM_IDS>(il, occ8 && !fpt, dedup, fpt), dim3((unsigned)blocks), dim3(threads), args, lds, s));
     HIP_TRY(hipGetLastError());
     *launched = true;
     return VET_OK;
@@ -597,7 +610,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
             int rc = choose_formulation(pl, k, want_table, U, s, &form[k]);
             if (rc) return rc;
         }
-        all_table = all_table && form[k] == F_TABLE;
+        all_table = all_table && (form[k] == F_TABLE || form[k] == F_FTABLE) && form[k] == form[0];
     }
     // ---- weighted, table formulation: every lattice in one launch
     if (all_table) {
@@ -606,7 +619,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         bool launched = false;
         int rc = launch_lut<FROM_IDS>(pl, idx, K, src, U, T, nullptr, 0, 0, 0, 0, d_entropy, d_assign, d_weights, d_present,
                                       d_status, s, &launched);
-        if (launched) for (int k = 0; k < K; ++k) pl->lat[k].last_form = F_TABLE;
+        if (launched) for (int k = 0; k < K; ++k) pl->lat[k].last_form = form[k];
         if (rc || launched) return rc;
         for (int k = 0; k < K; ++k) form[k] = sweep_formulation(pl, pl->lat[k], U);   // histograms do not fit the LDS
     }
@@ -617,13 +630,13 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
     }
     for (int k = 0; k < K; ++k) {
         const Lattice& L = pl->lat[k];
-        if (form[k] == F_TABLE) {
+        if (form[k] == F_TABLE || form[k] == F_FTABLE) {
             bool launched = false;
             int rc = launch_lut<FROM_IDS>(pl, &k, 1, src, U, T, nullptr, 0, 0, 0, 0, ent_k + (size_t)k * T,
                                           k == 0 ? d_assign : nullptr, k == 0 ? d_weights : nullptr,
                                           k == 0 ? d_present : nullptr, k == 0 ? d_status : nullptr, s, &launched);
             if (rc) return rc;
-            if (launched) { pl->lat[k].last_form = F_TABLE; continue; }
+            if (launched) { pl->lat[k].last_form = form[k]; continue; }
             form[k] = sweep_formulation(pl, L, U);
         }
         // binned lattices (naive tiling) are always integer counts; the flag picks the normaliser
@@ -1020,6 +1033,10 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
     for (int v = 0; v < 8; ++v) {
         PLAN_TRY(hipFuncSetAttribute(lut_kernel<false>(v & 1, v & 2, v & 4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
         PLAN_TRY(hipFuncSetAttribute(lut_kernel<true>(v & 1, v & 2, v & 4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+        if (!(v & 2)) {
+            PLAN_TRY(hipFuncSetAttribute(lut_kernel<false>(v & 1, false, v & 4, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+            PLAN_TRY(hipFuncSetAttribute(lut_kernel<true>(v & 1, false, v & 4, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+        }
     }
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
@@ -1054,6 +1071,7 @@ int vet_plan_destroy(vet_plan* pl) {
         if (L.d_tab_i) (void)hipFree(L.d_tab_i);
         if (L.d_tab_meta) (void)hipFree(L.d_tab_meta);
         if (L.d_row_s) (void)hipFree(L.d_row_s);
+        if (L.d_row_e) (void)hipFree(L.d_row_e);
     }
     if (pl->d_alias) (void)hipFree(pl->d_alias);
     if (pl->d_dirrec) (void)hipFree(pl->d_dirrec);
@@ -1203,11 +1221,13 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
     int max_users = 0;
     for (int v = 0; v < n_videos; ++v) max_users = videos[v].n_users > max_users ? videos[v].n_users : max_users;
     bool table = table_requested(pl, total, max_users);
+    int form0 = F_SWEEP;
     for (int k = 0; k < K && table; ++k) {
         int form = F_SWEEP;
         int rc = choose_formulation(pl, k, true, max_users, s, &form);
         if (rc) return rc;
-        table = form == F_TABLE;
+        if (k == 0) form0 = form;
+        table = (form == F_TABLE || form == F_FTABLE) && form == form0;      // one launch: tables of one kind
     }
     int n_sum = 0;
     for (int k = 0; k < K; ++k) n_sum += pl->lat[k].n;
@@ -1238,7 +1258,7 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
             for (int k = 0; k < K; ++k) idx[k] = k;
             const vet::SampleSrc src{nullptr, nullptr, nullptr, pl->W, pl->H, (long)pl->n_dirs};
             bool launched = false;
-            for (int k = 0; k < K; ++k) pl->lat[k].last_form = F_TABLE;
+            for (int k = 0; k < K; ++k) pl->lat[k].last_form = form0;
             return launch_lut<false>(pl, idx, K, src, 0, 0, (const vet::VideoDesc*)d_desc, n_videos, block, lds_max, max_users, nullptr,
                                      nullptr, nullptr, nullptr, d_status, s, &launched);
         }

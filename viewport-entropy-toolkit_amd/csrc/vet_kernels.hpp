@@ -470,6 +470,7 @@ struct StatsParams {
     double cos_cull;
     WeightCfg wc;
     uint8_t* row_s;             // [D+1] TAB_X + e per row (row D = the all-zero row)
+    uint16_t* row_e;            // [D+1] E = -(binary exponent of the row's largest weight), unclamped (FP table)
     unsigned long long* crit;   // [2] bit patterns of non-negative doubles (atomicMax):
                                 //   [0] max_d 36.5 q_d k_d / (S_d H_d)   with the table's q_d = 2^(e_d - 33)
                                 //   [1] max_d 36.5 k_d / (S_d H_d)       (times the sweep's step, 2^(shift-53))
@@ -503,6 +504,7 @@ __global__ void k_row_stats(const StatsParams p) {
         k = wave_sum(k); S = wave_sum(S); L = wave_sum(L); mx = wave_max(mx);
         int e = 0;
         if (mx > 0.0) (void)frexp(mx, &e);                  // mx <= 2^e
+        if (lane == 0) p.row_e[d] = (uint16_t)min(2047, max(0, -e));
         e = min(0, max(-TAB_X, e));
         if (lane == 0) p.row_s[d] = (uint8_t)(TAB_X + e);
         if (k >= 1) {
@@ -515,7 +517,7 @@ __global__ void k_row_stats(const StatsParams p) {
         }
     }
     if (lane == 0) {
-        if (p.row_s && wave == 0) p.row_s[p.D] = (uint8_t)TAB_X;
+        if (p.row_s && wave == 0) { p.row_s[p.D] = (uint8_t)TAB_X; p.row_e[p.D] = 0; }
         if (worst_tab > 0.0) atomicMax(&p.crit[0], (unsigned long long)__double_as_longlong(worst_tab));
         if (worst_sweep > 0.0) atomicMax(&p.crit[1], (unsigned long long)__double_as_longlong(worst_sweep));
     }
@@ -533,6 +535,8 @@ struct WtabParams {
     uint16_t* idx;
     uint32_t* meta;     // [D+1] entries in use per row | row shift << 16
     const uint8_t* row_s;
+    const uint16_t* row_e;
+    int fp;             // FP table: entries are FP32 weights scaled by 2^E of their row, meta field = E
     int* maxcount;
     int gs_log2;        // >= 0: well-filled blocks dealt over the 2^gs_log2 lanes of a gather group
 };
@@ -569,8 +573,8 @@ __global__ void k_wtab(const WtabParams p) {
     for (long d = wave; d < p.D; d += nwaves) {
         const double dx = p.dir_unit[3 * d], dy = p.dir_unit[3 * d + 1], dz = p.dir_unit[3 * d + 2];
         int count = 0;
-        const int row_shift = FILL ? (int)p.row_s[d] : 0;
-        const double scale = ldexp(1.0, 32 + TAB_X - row_shift);        // 2^(32 - e)
+        const int row_shift = FILL ? (p.fp ? (int)p.row_e[d] : (int)p.row_s[d]) : 0;
+        const double scale = p.fp ? ldexp(1.0, row_shift) : ldexp(1.0, 32 + TAB_X - row_shift);        // 2^E / 2^(32 - e)
         for (int t0 = 0; t0 < p.n; t0 += WAVE) {
             const int t = t0 + lane;
             const bool valid = t < p.n;
@@ -579,7 +583,10 @@ __global__ void k_wtab(const WtabParams p) {
             bool hit = valid && (c > p.cos_cull);
             unsigned w32 = 0u;
             if (FILL) {
-                if (hit) w32 = (unsigned)fmin(rint(fov_weight_exact(c, p.wc) * scale), 4294967295.0);
+                if (hit) {
+                    const double wt = fov_weight_exact(c, p.wc);
+                    w32 = p.fp ? __float_as_uint((float)(wt * scale)) : (unsigned)fmin(rint(wt * scale), 4294967295.0);
+                }
                 hit = w32 != 0u;
             }
             const unsigned long long mask = __ballot(hit);
@@ -660,7 +667,7 @@ __global__ void k_wtab(const WtabParams p) {
             // lane l of a 16-lane group adds its zeros to tile l: 16 classes, no conflict
             p.idx[p.D * p.stride + pos] = (uint16_t)(p.gs_log2 == 4 ? (pos >> 2) & 15 : pos % p.n);
         }
-        if (lane == 0) p.meta[p.D] = (uint32_t)TAB_X << 16;
+        if (lane == 0) p.meta[p.D] = p.fp ? 0u : (uint32_t)TAB_X << 16;
     }
 }
 
@@ -673,19 +680,21 @@ __global__ void k_wtab(const WtabParams p) {
 // ------------------------------------------------------------------------------------------
 // Per-direction record of the table kernel's prologue: one 8-byte gather per sample instead of three
 // (alias, nearest tile, row meta):  x = row (19 bits) | nearest tile bits 0..11 << 19 | mirrored << 31
-//                                     y = meta of the row in lattice 0 (21 bits) | nearest tile bits 12..15 << 21
+//                                     y = meta of the row in lattice 0 (28 bits) | nearest tile bits 12..15 << 28
 __global__ void k_dirrec(const uint32_t* __restrict__ alias, const uint16_t* __restrict__ nearest,
                          const uint32_t* __restrict__ meta0, long D, uint2* __restrict__ rec) {
     for (long d = blockIdx.x * (long)blockDim.x + threadIdx.x; d < D; d += (long)gridDim.x * blockDim.x) {
         const uint32_t a = alias[d], near = nearest[d], row = a & 0x7FFFFu;
-        rec[d] = make_uint2(row | ((near & 0xFFFu) << 19) | (a & 0x80000000u), (meta0[row] & 0x1FFFFFu) | ((near >> 12) << 21));
+        rec[d] = make_uint2(row | ((near & 0xFFFu) << 19) | (a & 0x80000000u), (meta0[row] & 0xFFFFFFFu) | ((near >> 12) << 28));
     }
 }
 
 constexpr int ROW_BITS = 19;
 constexpr uint32_t ROW_MASK = (1u << ROW_BITS) - 1;
 
-template <int UN, bool INTERLEAVED, bool DEDUP>
+// FPT: FP table — entries are FP32 weights (relative precision 2^-24 each: |dH|/H <= 1.2e-7 for every frame, whatever the
+// weights' dynamic range), scaled by 2^E of their row; the histogram is FP64 (ds_add_f64) in true units.
+template <int UN, bool INTERLEAVED, bool DEDUP, bool FPT>
 __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t* fmeta, int nu,
                                           unsigned long long* hrow, int n,
                                           const uint32_t* __restrict__ tab_w, const uint16_t* __restrict__ tab_i,
@@ -703,6 +712,7 @@ __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t*
         int len[UN], sgn[UN];
         char* hb[UN];
         uint32_t mult[UN];
+        double scale[UN];
         int longest = 0;
 #pragma unroll
         for (int k = 0; k < UN; ++k) {
@@ -715,7 +725,9 @@ __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t*
             const uint32_t rid = DEDUP ? key & ROW_MASK : key & 0x7FFFFFFFu;
             row[k] = on ? (long)rid * stride : zero_row;
             len[k] = (int)(m & 0xFFFFu);
-            mult[k] = (DEDUP ? pk & 0xFFFu : (on ? 1u : 0u)) << (m >> 16);
+            const uint32_t cnt = DEDUP ? pk & 0xFFFu : (on ? 1u : 0u);
+            mult[k] = FPT ? cnt : cnt << ((m >> 16) & 0xFFFu);
+            if (FPT) scale[k] = ldexp((double)cnt, -(int)((m >> 16) & 0xFFFu));
             sgn[k] = flip ? -8 : 8;
             hb[k] = (char*)hrow + (flip ? (n - 1) * 8 : 0);
             longest = max(longest, len[k]);
@@ -751,10 +763,17 @@ __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t*
             }
 #pragma unroll
             for (int k = 0; k < UN; ++k) {
-                atomicAdd((unsigned long long*)(hb[k] + (int)t[k].x * sgn[k]), (unsigned long long)w[k].x * mult[k]);
-                atomicAdd((unsigned long long*)(hb[k] + (int)t[k].y * sgn[k]), (unsigned long long)w[k].y * mult[k]);
-                atomicAdd((unsigned long long*)(hb[k] + (int)t[k].z * sgn[k]), (unsigned long long)w[k].z * mult[k]);
-                atomicAdd((unsigned long long*)(hb[k] + (int)t[k].w * sgn[k]), (unsigned long long)w[k].w * mult[k]);
+                if (FPT) {
+                    atomicAdd((double*)(hb[k] + (int)t[k].x * sgn[k]), (double)__uint_as_float(w[k].x) * scale[k]);
+                    atomicAdd((double*)(hb[k] + (int)t[k].y * sgn[k]), (double)__uint_as_float(w[k].y) * scale[k]);
+                    atomicAdd((double*)(hb[k] + (int)t[k].z * sgn[k]), (double)__uint_as_float(w[k].z) * scale[k]);
+                    atomicAdd((double*)(hb[k] + (int)t[k].w * sgn[k]), (double)__uint_as_float(w[k].w) * scale[k]);
+                } else {
+                    atomicAdd((unsigned long long*)(hb[k] + (int)t[k].x * sgn[k]), (unsigned long long)w[k].x * mult[k]);
+                    atomicAdd((unsigned long long*)(hb[k] + (int)t[k].y * sgn[k]), (unsigned long long)w[k].y * mult[k]);
+                    atomicAdd((unsigned long long*)(hb[k] + (int)t[k].z * sgn[k]), (unsigned long long)w[k].z * mult[k]);
+                    atomicAdd((unsigned long long*)(hb[k] + (int)t[k].w * sgn[k]), (unsigned long long)w[k].w * mult[k]);
+                }
             }
         }
     }
@@ -842,7 +861,7 @@ __host__ __device__ __forceinline__ size_t lut_lds_bytes(int U, int UC, int FPW,
 // 2 % (random walk) to 6.5 % (clustered) faster on single-lattice plans and 7 % on batches of short
 // videos, but 2-4 % slower on one multi-lattice video (profiles/r01/v6_table_occupancy.log).
 // DEDUP: per-frame set of distinct rows with multiplicities (direction tables of < 2^20 rows).
-template <bool FROM_IDS, int UN, bool IL, bool OCC8, bool DEDUP>
+template <bool FROM_IDS, int UN, bool IL, bool OCC8, bool DEDUP, bool FPT>
 __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // the video this workgroup works on: the launch's only one, or one of a batch
@@ -935,13 +954,13 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
                     if (DEDUP) {
                         const uint2 rec = p.dirrec[id[k]];
                         row[k] = (rec.x & ROW_MASK) | ((rec.x >> 31) << ROW_BITS);
-                        near[k] = (int)(((rec.x >> ROW_BITS) & 0xFFFu) | ((rec.y >> 21) << 12));
-                        m0[k] = rec.y & 0x1FFFFFu;
+                        near[k] = (int)(((rec.x >> ROW_BITS) & 0xFFFu) | ((rec.y >> 28) << 12));
+                        m0[k] = rec.y & 0xFFFFFFFu;
                     } else if (p.dirrec) {                      // small frames: no set, but the fused record
                         const uint2 rec = p.dirrec[id[k]];
                         row[k] = (rec.x & ROW_MASK) | (rec.x & 0x80000000u);
-                        near[k] = (int)(((rec.x >> ROW_BITS) & 0xFFFu) | ((rec.y >> 21) << 12));
-                        m0[k] = rec.y & 0x1FFFFFu;
+                        near[k] = (int)(((rec.x >> ROW_BITS) & 0xFFFu) | ((rec.y >> 28) << 12));
+                        m0[k] = rec.y & 0xFFFFFFFu;
                     } else {
                         row[k] = p.alias[id[k]];                // canonical row | mirrored << 31
                         if (assign) near[k] = (int)p.nearest[id[k]];
@@ -1029,11 +1048,11 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
             __syncthreads();
             for (int fl = 0; fl < nf; ++fl)
                 if (IL && L.interleaved)
-                    walk_rows<UN, true, DEDUP>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
+                    walk_rows<UN, true, DEDUP, FPT>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
                                                hist + (size_t)fl * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
                                                (long)src.n_dirs * L.stride);
                 else
-                    walk_rows<UN, false, DEDUP>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
+                    walk_rows<UN, false, DEDUP, FPT>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
                                                 hist + (size_t)fl * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
                                                 (long)src.n_dirs * L.stride);
             hoff += L.n;
@@ -1049,16 +1068,16 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
             const int n = p.lat[k].n;
             // total weight can exceed 64 bits of fixed point: summed in FP64, fixed lane order + butterfly
             double totd = 0.0;
-            for (int t = lane; t < n; t += WAVE) totd += (double)hrow[t];
+            for (int t = lane; t < n; t += WAVE) totd += FPT ? __longlong_as_double((long long)hrow[t]) : (double)hrow[t];
             totd = wave_sum(totd);
             double h = 0.0;
             for (int t = lane; t < n; t += WAVE) {
-                const unsigned long long v = hrow[t];
-                if (v) {
-                    const double q = (double)v / totd;
+                const double v = FPT ? __longlong_as_double((long long)hrow[t]) : (double)hrow[t];
+                if (v != 0.0) {
+                    const double q = v / totd;
                     h -= q * log2(q);
                 }
-                if (k == 0 && weights) __builtin_nontemporal_store((double)v * inv_unit, weights + (f0 + fl) * (long)n + t);
+                if (k == 0 && weights) __builtin_nontemporal_store(FPT ? v : v * inv_unit, weights + (f0 + fl) * (long)n + t);
             }
             h = wave_sum(h);
             total_entropy += h / p.lat[k].hmax;

@@ -341,8 +341,8 @@ class Plan:
         return int(self.lib.vet_plan_table_stride(self.handle, lattice))
 
     def last_formulation(self, lattice: int = 0) -> str:
-        """'table' | 'sweep' | 'precise' of the last weighted call ('' before any)."""
-        return {0: "table", 1: "sweep", 2: "precise"}.get(int(self.lib.vet_plan_last_formulation(self.handle, lattice)), "")
+        """'table' | 'sweep' | 'precise' | 'ftable' of the last weighted call ('' before any)."""
+        return {0: "table", 1: "sweep", 2: "precise", 3: "ftable"}.get(int(self.lib.vet_plan_last_formulation(self.handle, lattice)), "")
 
     def error_bounds(self, lattice: int = 0):
         """(table bound, sweep bound): proven worst-case relative entropy error of the integer formulations."""
