@@ -1427,6 +1427,7 @@ __device__ __forceinline__ void trans_init(unsigned* tile_words, int n4, unsigne
 }
 
 // step (5) and the row's outputs; all threads call it after step (4) is visible
+template <bool LDS_ONLY>      // LDS_ONLY: the row's shared words are all in LDS, the barrier need not drain global loads
 __device__ __forceinline__ void trans_cells(const TransParams& p, long r, const unsigned* first_u, const unsigned* m_cnt,
                                             const unsigned* k_cnt, double* acc, bool tab) {
     const int tid = threadIdx.x, NW = blockDim.x >> 6;
@@ -1445,7 +1446,7 @@ __device__ __forceinline__ void trans_cells(const TransParams& p, long r, const 
     }
     h = wave_sum(h);
     if (lane_id() == 0) acc[wave_id()] = h;
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
     if (tid == 0) {
         double tot = 0.0;
         for (int i = 0; i < NW; ++i) tot += acc[i];
@@ -1548,7 +1549,7 @@ __global__ void k_transition_any(const TransParams p) {
             if (sl < 0x40000000u && last_fu[pc[u] >> 16] == (unsigned)u) first_u[pc[u] >> 16] = hcnt[sl];
         }
         __syncthreads();
-        trans_cells(p, r, first_u, m_cnt, k_cnt, acc, tab);
+        trans_cells<false>(p, r, first_u, m_cnt, k_cnt, acc, tab);
     }
     if (p.status) {
         const unsigned long long anybad = __ballot(bad);
@@ -1622,8 +1623,9 @@ __global__ void k_transition_run(const TransParams p) {
         double* acc = acc2 + TRANS_ACC * parity;
         trans_init(first_u, n4, hkey, hfu, hcnt, p.HS, acc);      // the barrier inside trans_cells of the previous row precedes
         tiles_of(cur);
-        if (r + 1 < r_end) request(r + 2);         // in flight during this row's LDS phases
-        __syncthreads();
+        if (r + 1 < r_end) request(r + 2);         // in flight during this row's LDS phases: the barriers below wait for
+                                                   // LDS traffic only (lds_barrier), not for these loads
+        lds_barrier();
         unsigned key[UPT];
         int present = 0;
 #pragma unroll
@@ -1644,7 +1646,7 @@ __global__ void k_transition_run(const TransParams p) {
         }
         if (pairs_row) pairs_row += 2 * (long)p.U;
         if (lane == 0 && present) atomicAdd((unsigned long long*)acc + 16, (unsigned long long)present);
-        __syncthreads();
+        lds_barrier();
         unsigned slot[UPT];
         bool nonfirst[UPT];
 #pragma unroll
@@ -1665,21 +1667,21 @@ __global__ void k_transition_run(const TransParams p) {
                 slot[k] = h;
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int k = 0; k < UPT; ++k) {
             const unsigned u = (unsigned)(tid + k * (int)blockDim.x);
             if (nonfirst[k] && hfu[slot[k]] == u) atomicMax(&last_fu[key[k] >> 16], u);
         }
-        __syncthreads();
+        lds_barrier();
         // w of a source tile = count of the bucket whose first user is last_fu: that user publishes it
 #pragma unroll
         for (int k = 0; k < UPT; ++k) {
             const unsigned u = (unsigned)(tid + k * (int)blockDim.x);
             if (nonfirst[k] && last_fu[key[k] >> 16] == u) first_u[key[k] >> 16] = hcnt[slot[k]];   // first_u is free now
         }
-        __syncthreads();
-        trans_cells(p, r, first_u, m_cnt, k_cnt, acc, true);
+        lds_barrier();
+        trans_cells<true>(p, r, first_u, m_cnt, k_cnt, acc, true);
 #pragma unroll
         for (int k = 0; k < UPT; ++k) prev[k] = cur[k];
     }
