@@ -124,6 +124,55 @@ def test_one_rank_rccl_gather():
     assert q.get(timeout=10) == (True, True, True)
 
 
+def _stream_worker(q):
+    _paths()
+    import torch
+    from viewport_entropy_toolkit import _synthetic
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    eng, plan = _make_plans()
+    mu_h, mv_h = _synthetic.random_walk_video(64, 4000, base_seed=2)
+    want = plan.spatial(mu=mu_h, mv=mv_h, want_assign=False)["entropy"]
+    mu, mv = torch.from_numpy(mu_h).to(dev), torch.from_numpy(mv_h).to(dev)
+    ok = []
+    # (a) torch's default stream (handle 0 -> VET_STREAM_LEGACY): the clone is enqueued behind the kernel on the same stream
+    ent = torch.zeros(4000, dtype=torch.float64, device=dev)
+    plan.spatial_device(mu.data_ptr(), mv.data_ptr(), 64, 4000, ent.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    got = ent.clone()
+    torch.cuda.synchronize()
+    ok.append(bool(np.array_equal(got.cpu().numpy(), want)))
+    # (b) an explicit non-default stream: kernel and consumer on that stream
+    st = torch.cuda.Stream(device=dev)
+    ent2 = torch.zeros(4000, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        plan.spatial_device(mu.data_ptr(), mv.data_ptr(), 64, 4000, ent2.data_ptr(), stream=st.cuda_stream)
+        got2 = ent2.clone()
+    st.synchronize()
+    ok.append(bool(np.array_equal(got2.cpu().numpy(), want)))
+    # (c) stream=None: the engine's own stream, made visible by Engine.synchronize()
+    ent3 = torch.zeros(4000, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    plan.spatial_device(mu.data_ptr(), mv.data_ptr(), 64, 4000, ent3.data_ptr())
+    eng.synchronize()
+    ok.append(bool(np.array_equal(ent3.cpu().numpy(), want)))
+    q.put(tuple(ok))
+    plan.close()
+
+
+def test_device_pointer_calls_on_torch_streams():
+    """`stream` of the device-pointer entry points (include/vet.h): torch's default stream (handle 0) is the legacy null
+    stream, an explicit stream is used as is, None is the engine's own stream."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_stream_worker, args=(q,))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert q.get(timeout=10) == (True, True, True)
+
+
 @pytest.mark.parametrize("workload,shard", [("config2", "videos"), ("config5", "frames")])
 def test_bench_launches_its_own_ranks(workload, shard):
     """`python bench.py --gpus 2` with no outer launcher: two ranks, n_gpus = 2 in the line (gloo rehearsal on
