@@ -713,8 +713,10 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
 }
 
 template <bool FROM_IDS>
-const void* transition_run_kernel(int upt, bool exact) {
-#define VET_PICK(N) if (upt == N) return exact ? (const void*)vet::k_transition_run<FROM_IDS, N, true> : (const void*)vet::k_transition_run<FROM_IDS, N, false>
+const void* transition_run_kernel(int upt, bool exact, int threads) {
+    // the default workgroup of up to 512 users (128 threads) has its size compiled in
+#define VET_PICK(N) if (upt == N) return threads == 128 ? (exact ? (const void*)vet::k_transition_run<FROM_IDS, N, true, 128> : (const void*)vet::k_transition_run<FROM_IDS, N, false, 128>) \
+                                                        : (exact ? (const void*)vet::k_transition_run<FROM_IDS, N, true, 0> : (const void*)vet::k_transition_run<FROM_IDS, N, false, 0>)
     VET_PICK(1); VET_PICK(2); VET_PICK(4); VET_PICK(8);
 #undef VET_PICK
     return nullptr;
@@ -740,7 +742,7 @@ int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, dou
         const Lattice& L = pl->lat[k];
         const size_t n4 = ((size_t)L.n + 3) & ~(size_t)3;
         const size_t lds_tiles = 2 * 20 * 8 + 4 * n4 * 4;
-        const size_t lds_run = lds_tiles + (size_t)3 * HS * 4;
+        const size_t lds_run = lds_tiles + (size_t)3 * HS * 4 + ((size_t)U + 2) * 8;     // + log2(k), k <= U
         const size_t lds_cap = 160 * 1024 - 512;     // a single workgroup may take the whole LDS
         if (lds_tiles > lds_cap)
             return fail(VET_ERR_UNSUPPORTED, "transition kernel: %d tiles need %zu B of LDS (max %zu)", L.n, lds_tiles, lds_cap);
@@ -758,6 +760,7 @@ int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, dou
         p.HS = HS; p.hs_shift = 32 - lg;
         p.log2_tab = c->d_log2;
         p.scratch = nullptr;
+        p.run_q = 0; p.run_r = 0;
         ProfScope ps(c, s, KID_TRANSITION);
         if (U <= 4096 && lds_run <= lds_cap && !getenv("VET_T_GLOBAL")) {
             // persistent workgroups over contiguous runs of rows (k_transition_run); users per thread 1, 2, 4 or 8:
@@ -773,7 +776,8 @@ int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, dou
             per_cu = env_int("VET_T_WGS_PER_CU", 1, 16, (int)(per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu)));
             long grid = (long)c->n_cu * per_cu;
             if (grid > R) grid = R;
-            const void* fn = transition_run_kernel<FROM_IDS>(upt, (long)upt * threads == U);
+            p.run_q = (int)(R / grid); p.run_r = (int)(R % grid);
+            const void* fn = transition_run_kernel<FROM_IDS>(upt, (long)upt * threads == U, threads);
             void* args[] = {(void*)&p};
             HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(threads), args, lds_run, s));
         } else {
@@ -1047,10 +1051,11 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
     {
         std::vector<const void*> tk = {(const void*)vet::k_transition_any<false>, (const void*)vet::k_transition_any<true>};
         for (int upt : {1, 2, 4, 8})
-            for (int ex = 0; ex < 2; ++ex) {
-                tk.push_back(transition_run_kernel<false>(upt, ex != 0));
-                tk.push_back(transition_run_kernel<true>(upt, ex != 0));
-            }
+            for (int ex = 0; ex < 2; ++ex)
+                for (int threads : {128, 0}) {
+                    tk.push_back(transition_run_kernel<false>(upt, ex != 0, threads));
+                    tk.push_back(transition_run_kernel<true>(upt, ex != 0, threads));
+                }
         for (const void* f : tk) PLAN_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
     }
 #undef PLAN_TRY
