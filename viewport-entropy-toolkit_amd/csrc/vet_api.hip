@@ -409,7 +409,8 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     const size_t bytes = rows * stride * 6 + rows * 4;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = kMaxTableBytes;
-    if (stride > 65535 || bytes > kMaxTableBytes || bytes + ((size_t)64 << 20) > free_b) { L.stride = -1; return VET_OK; }
+    // (the gather addresses entries with 32-bit offsets: fewer than 2^32 of them)
+    if (stride > 65535 || bytes > kMaxTableBytes || rows * (size_t)stride >= ((size_t)1 << 32) || bytes + ((size_t)64 << 20) > free_b) { L.stride = -1; return VET_OK; }
     // a failed earlier attempt may have left buffers behind
     auto drop = [&]() {
         if (L.d_tab_w) { (void)hipFree(L.d_tab_w); L.d_tab_w = nullptr; }

@@ -698,18 +698,22 @@ template <int UN, bool INTERLEAVED, bool DEDUP, bool FPT>
 __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t* fmeta, int nu,
                                           unsigned long long* hrow, int n,
                                           const uint32_t* __restrict__ tab_w, const uint16_t* __restrict__ tab_i,
-                                          int stride, int gs_log2, long zero_row) {
+                                          int stride, int gs_log2_rt, uint32_t zero_row) {
     // Every lane takes one 4-slot chunk per block: one 16-byte load of weights, one 8-byte load of
     // tiles (stride is a multiple of the block, so chunks are 16 / 8 byte aligned), then four
     // unconditional ds_add_u64 of entry * (multiplicity << row shift): padding slots and idle lanes
     // (which walk the all-zero row) add 0 to distinct tiles — no predicates around the adds.
     const int NW = blockDim.x >> 6, lane = lane_id(), wv = wave_id();
+    const int gs_log2 = INTERLEAVED ? 4 : gs_log2_rt;       // class-dealt rows are 16-lane rows (ensure_wtab)
     const int GS = 1 << gs_log2, UPW = WAVE >> gs_log2;
     const int sub = lane >> gs_log2, sl = lane & (GS - 1);
     const int step = NW * UPW;
+    // the lane's chunk of block eb holds entries eb + 4*sl + {0..3} (plain block) or eb + sl + GS*{0..3} (class-dealt
+    // block: every block with at least 3/4 of its slots in use): it has work while eb < len - cut
+    const int cut = INTERLEAVED ? min(4 * sl, 3 * GS - 1) : 4 * sl;
     for (int j0 = wv * UPW; j0 < nu; j0 += UN * step) {
-        long row[UN];
-        int len[UN], sgn[UN];
+        uint32_t row[UN];                 // entry offsets: a table holds fewer than 2^32 entries (ensure_wtab)
+        int lim[UN], sgn[UN];
         char* hb[UN];
         uint32_t mult[UN];
         double scale[UN];
@@ -723,43 +727,34 @@ __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t*
             // a mirrored direction (x,-y,-z) walks its partner's row into the mirrored tiles n-1-t
             const bool flip = ((DEDUP ? key >> ROW_BITS : key >> 31) & 1u) != 0u;
             const uint32_t rid = DEDUP ? key & ROW_MASK : key & 0x7FFFFFFFu;
-            row[k] = on ? (long)rid * stride : zero_row;
-            len[k] = (int)(m & 0xFFFFu);
+            row[k] = on ? rid * (uint32_t)stride : zero_row;
+            const int len = (int)(m & 0xFFFFu);
+            lim[k] = len - cut;
             const uint32_t cnt = DEDUP ? pk & 0xFFFu : (on ? 1u : 0u);
             mult[k] = FPT ? cnt : cnt << ((m >> 16) & 0xFFFu);
             if (FPT) scale[k] = ldexp((double)cnt, -(int)((m >> 16) & 0xFFFu));
             sgn[k] = flip ? -8 : 8;
             hb[k] = (char*)hrow + (flip ? (n - 1) * 8 : 0);
-            longest = max(longest, len[k]);
+            longest = max(longest, len);
         }
-        // block base eb counts sorted entries; the lane's chunk sits at slots eb + 4*sl .. +3 and holds
-        // entries eb + 4*sl + {0..3} (plain block) or eb + sl + GS*{0..3} (interleaved block)
         for (int eb = 0; eb < longest; eb += 4 * GS) {
-            const int e = eb + 4 * sl;
-            long r[UN];
-            if (INTERLEAVED) {
-                bool any = false;
+            // a row that has ended reads the all-zero row (same slots, one hot line) instead of its own padding
+            // lines: the gather is bound by cache lines touched (TA/TD busy)
+            uint32_t r[UN];
+            bool any = false;
 #pragma unroll
-                for (int k = 0; k < UN; ++k) {
-                    const int first = block_interleaved(len[k], eb, gs_log2) ? eb + sl : e;
-                    const bool on = first < len[k];
-                    r[k] = on ? row[k] : zero_row;
-                    any = any || on;
-                }
-                if (!any) continue;
-            } else {
-                if (e >= longest) break;
-                // a row that has ended reads the all-zero row (same slots, one hot line) instead of
-                // its own padding lines: the gather is bound by cache lines touched (TA/TD busy)
-#pragma unroll
-                for (int k = 0; k < UN; ++k) r[k] = e < len[k] ? row[k] : zero_row;
+            for (int k = 0; k < UN; ++k) {
+                const bool on = eb < lim[k];
+                r[k] = (on ? row[k] : zero_row) + (uint32_t)(eb + 4 * sl);
+                any = any || on;
             }
+            if (!any) continue;
             uint4 w[UN];
             ushort4 t[UN];
 #pragma unroll
             for (int k = 0; k < UN; ++k) {
-                w[k] = *(const uint4*)(tab_w + r[k] + e);
-                t[k] = *(const ushort4*)(tab_i + r[k] + e);
+                w[k] = *(const uint4*)(tab_w + r[k]);
+                t[k] = *(const ushort4*)(tab_i + r[k]);
             }
 #pragma unroll
             for (int k = 0; k < UN; ++k) {
@@ -1050,11 +1045,11 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
                 if (IL && L.interleaved)
                     walk_rows<UN, true, DEDUP, FPT>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
                                                hist + (size_t)fl * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
-                                               (long)src.n_dirs * L.stride);
+                                               (uint32_t)src.n_dirs * (uint32_t)L.stride);
                 else
                     walk_rows<UN, false, DEDUP, FPT>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
                                                 hist + (size_t)fl * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
-                                                (long)src.n_dirs * L.stride);
+                                                (uint32_t)src.n_dirs * (uint32_t)L.stride);
             hoff += L.n;
         }
     }
