@@ -1,0 +1,29 @@
+#!/bin/bash
+# usage: tools/refresh_profiles.sh TAG   (on the GPU box, from the repo root)
+# Everything profiles/rNN/ holds about the current kernel sources, in one call: HBM traffic passes
+# (pmc_traffic.sh), one bench line per workload / sample distribution, and the default bench under
+# rocprofv3 --kernel-trace --stats.  Results land in gpurun_out/TAG/; copy them to profiles/rNN/.
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"
+TAG=$1
+mkdir -p gpurun_out/$TAG
+bash tools/pmc_traffic.sh $TAG/pmc config3 config3u config4 config5 > gpurun_out/$TAG/pmc_traffic.log 2>&1 || { echo "pmc_traffic failed"; tail -5 gpurun_out/$TAG/pmc_traffic.log; exit 1; }
+cp gpurun_out/$TAG/pmc/pmc_traffic.json profiles/pmc_traffic.json      # bench.py reads it from there
+line() { # name, args...
+  local name=$1; shift
+  timeout -k 10 300 python3 bench.py "$@" > gpurun_out/$TAG/bench_$name.json 2> gpurun_out/$TAG/bench_$name.err || { echo "bench $name failed"; tail -3 gpurun_out/$TAG/bench_$name.err; return 1; }
+  echo "bench $name ok"
+}
+line config3 --workload config3 || exit 1
+for d in clustered uniform; do line config3_$d --workload config3 --data $d --no-cpu-baseline || exit 1; done
+line config3u --workload config3u --no-cpu-baseline || exit 1
+line config5 --workload config5 --steps 50 --no-cpu-baseline || exit 1
+for d in clustered uniform; do line config5_$d --workload config5 --steps 50 --data $d --no-cpu-baseline || exit 1; done
+line config4 --workload config4 --no-cpu-baseline || exit 1
+line config2 --workload config2 --steps 50 --no-cpu-baseline || exit 1
+line config2x64 --workload config2x64 --no-cpu-baseline || exit 1
+line defaults --workload defaults --no-cpu-baseline || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/default_trace -- python3 bench.py --no-cpu-baseline --no-api > gpurun_out/$TAG/default_bench_under_rocprof.json 2> gpurun_out/$TAG/default_trace.err || { echo "rocprof default bench failed"; exit 1; }
+cp $(ls gpurun_out/$TAG/default_trace/*/*_kernel_stats.csv | head -1) gpurun_out/$TAG/default_bench_kernel_stats.csv
+for w in config3 config3u config4 config5; do cp $(ls gpurun_out/$TAG/pmc/$w/trace/*/*_kernel_stats.csv | head -1) gpurun_out/$TAG/pmc_${w}_kernel_stats.csv; done
+echo "refresh done"
