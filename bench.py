@@ -238,6 +238,12 @@ def main():
         vids = (_native.Video * n_batch)(*[_native.Video(mus[v].data_ptr(), mvs[v].data_ptr(), U, T, ents[v].data_ptr(),
                                                          idxs[v].data_ptr(), None) for v in range(n_batch)])
 
+    pipelined = multi and backend == "nccl" and n_batch == 1 and not os.environ.get("VET_BENCH_SYNC_GATHER")
+    ent_bufs = [ent, torch.empty_like(ent)] if pipelined else [ent]
+    send_bufs = [send, (torch.zeros_like(send) if send is not ent else ent_bufs[1])] if pipelined else [send]
+    in_flight = [None, None]
+    step_no = [0]
+
     def step():
         if n_batch > 1:
             if args.loop:
@@ -249,18 +255,34 @@ def main():
             if multi:
                 dist.gather(ents[0], gathered, dst=0)
             return
+        # RCCL: the gather of step i runs on the process group's stream while the kernel of step i + 1 computes
+        # into the other entropy buffer; a buffer is handed to a kernel again only after the gather that read it
+        # two steps earlier has completed (a stream-level wait, the host does not block)
+        b = step_no[0] & 1 if pipelined else 0
+        step_no[0] += 1
+        e_buf, s_buf = ent_bufs[b], send_bufs[b]
+        if in_flight[b] is not None:
+            in_flight[b].wait()
+            in_flight[b] = None
         if mode == "spatial":
-            plan.spatial_device(mu.data_ptr(), mv.data_ptr(), U, T, ent.data_ptr(), d_assign=idx.data_ptr(),
+            plan.spatial_device(mu.data_ptr(), mv.data_ptr(), U, T, e_buf.data_ptr(), d_assign=idx.data_ptr(),
                                 d_status=status.data_ptr(), stream=stream)
         else:
-            plan.transition_device(mu.data_ptr(), mv.data_ptr(), U, T, ent.data_ptr(), d_pairs=idx.data_ptr(),
+            plan.transition_device(mu.data_ptr(), mv.data_ptr(), U, T, e_buf.data_ptr(), d_pairs=idx.data_ptr(),
                                    d_status=status.data_ptr(), stream=stream)
         if multi:
-            if send is not ent:
-                send[:R].copy_(ent)
-            dist.gather(send if backend == "nccl" else send.cpu(), gathered, dst=0)
+            if s_buf is not e_buf:
+                s_buf[:R].copy_(e_buf)
+            if pipelined:
+                in_flight[b] = dist.gather(s_buf, gathered, dst=0, async_op=True)
+            else:
+                dist.gather(s_buf if backend == "nccl" else s_buf.cpu(), gathered, dst=0)
 
     def fence():
+        for b in range(2):
+            if in_flight[b] is not None:
+                in_flight[b].wait()
+                in_flight[b] = None
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
@@ -297,6 +319,10 @@ def main():
     assert int(status.sum().item()) == 0, "engine flagged out-of-range samples or empty frames"
     e_host = (ents[-1] if n_batch > 1 else ent).cpu().numpy()
     assert np.isfinite(e_host).all()
+    if pipelined:       # both buffers hold the same series (same input every step)
+        assert np.array_equal(ent_bufs[1].cpu().numpy(), e_host, equal_nan=True)
+        if rank == 0:
+            assert np.array_equal(gathered[0][:R].cpu().numpy(), e_host, equal_nan=True), "gathered series differs from the local one"
 
     if rank == 0:
         samples_per_step = (U * T_total if strong else U * T * world) * n_batch

@@ -188,3 +188,23 @@ def test_bench_launches_its_own_ranks(workload, shard):
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["value"] > 0
     assert rec["scaling"] == ("strong" if shard == "frames" else "weak")
+
+
+@pytest.mark.parametrize("workload", ["config2", "config5"])
+def test_bench_rccl_pipelined_gather(workload):
+    """The driver's launch line with one rank: bench.py under torch.distributed.run takes the RCCL branch, where the
+    gather of a step overlaps the next step's kernel (two entropy buffers); the line must come out and the series
+    gathered on rank 0 must equal the local one (asserted inside bench.py)."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "VET_BENCH_BACKEND"):
+        env.pop(k, None)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"),
+                          "--gpus", "1", "--steps", "5", "--warmup", "2", "--workload", workload, "--no-cpu-baseline",
+                          "--no-api"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0

@@ -66,6 +66,7 @@ struct vet_ctx {
     void* ws = nullptr;
     size_t ws_bytes = 0;
     double* d_log2 = nullptr;      // log2(k), k = 0..4096
+    bool attrs_set = false;        // dynamic-LDS limits of the run kernels raised (first plan)
     // grow-only device staging buffers of the host-buffer entry points (no hipMalloc per call)
     void* pool[10] = {};
     size_t pool_cap[10] = {};
@@ -329,8 +330,14 @@ int ensure_alias(vet_plan* pl) {
             if (!(a & 0x80000000u) && a != d) alias[d] = alias[a];
         }
     }
-    HIP_TRY(hipMalloc((void**)&pl->d_alias, D * sizeof(uint32_t)));
-    HIP_TRY(hipMemcpy(pl->d_alias, alias.data(), D * sizeof(uint32_t), hipMemcpyHostToDevice));
+    uint32_t* d_alias = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_alias, D * sizeof(uint32_t)));
+    const hipError_t e = hipMemcpy(d_alias, alias.data(), D * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d_alias);
+        return fail(VET_ERR_DEVICE, "alias table upload failed: %s", hipGetErrorString(e));
+    }
+    pl->d_alias = d_alias;
     return VET_OK;
 }
 
@@ -836,17 +843,25 @@ int vet_create(int device_id, vet_ctx** out) {
                     e == hipSuccess ? "0 devices" : hipGetErrorString(e));
     if (device_id < 0 || device_id >= n) return fail(VET_ERR_INVALID, "device_id %d out of range [0,%d)", device_id, n);
     HIP_TRY(hipSetDevice(device_id));
-    vet_ctx* c = new vet_ctx();
-    c->device = device_id;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    vet_ctx* c = new vet_ctx();
+    c->device = device_id;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     // keep two workgroups per CU resident: cap a workgroup at half of the 160 KiB LDS
     c->lds_max = prop.sharedMemPerBlock >= 160 * 1024 ? 80 * 1024 : (size_t)prop.sharedMemPerBlock;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc((void**)&c->d_log2, 4097 * sizeof(double)));
-    hipLaunchKernelGGL(vet::k_log2_table, dim3(17), dim3(256), 0, c->stream, c->d_log2, 4097);
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_log2, 4097 * sizeof(double));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(vet::k_log2_table, dim3(17), dim3(256), 0, c->stream, c->d_log2, 4097);
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (e != hipSuccess) {
+        if (c->d_log2) (void)hipFree(c->d_log2);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(VET_ERR_DEVICE, "context set-up failed: %s", hipGetErrorString(e));
+    }
     *out = c;
     return VET_OK;
 }
@@ -1026,7 +1041,8 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
         PLAN_TRY(hipGetLastError());
     }
     PLAN_TRY(hipStreamSynchronize(s));
-    // the run kernels may need more than the default 64 KiB of dynamic LDS
+    // the run kernels may need more than the default 64 KiB of dynamic LDS (set once per context)
+    if (!c->attrs_set) {
     for (int R = 1; R <= 2; ++R) {
         for (int wm = 0; wm < 3; ++wm) {
             PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<false>(wm, R), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
@@ -1058,6 +1074,8 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
                     tk.push_back(transition_run_kernel<true>(upt, ex != 0, threads));
                 }
         for (const void* f : tk) PLAN_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+    }
+    c->attrs_set = true;
     }
 #undef PLAN_TRY
     *out = pl;
