@@ -85,7 +85,9 @@ def test_other_pixel_grids(native, engine, W, H, tc, weighted):
 
 
 @pytest.mark.parametrize("U,T,tcs", [(1500, 6, [50]), (4096, 3, [20]), (3, 30, [20, 50, 100]), (2, 2, [1000]),
-                                     (9000, 3, [20]), (20000, 2, [200]), (5000, 4, [50, 20])])
+                                     (9000, 3, [20]), (20000, 2, [200]), (5000, 4, [50, 20]),
+                                     # lanes without a user in the run kernel (1, 2 and 4 users per lane), an exact fit
+                                     (300, 9, [200]), (129, 5, [50]), (640, 4, [100]), (512, 7, [200]), (64, 40, [20])])
 def test_transition_shapes(native, engine, U, T, tcs):
     mu, mv = video(U, T, seed=U + 7 * T, p_absent=0.05)
     mu[:, 0] = np.where(np.isnan(mu[:, 0]), 0.5, mu[:, 0])      # user 0 always present: no empty rows
