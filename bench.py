@@ -79,8 +79,9 @@ def kernel_src_sha():
     """Hash of the device code: PMC records are only valid for the sources they were measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("vet_kernels.hpp", "vet_api.hip"):
-        h.update((ROOT / "viewport-entropy-toolkit_amd" / "csrc" / f).read_bytes())
+    csrc = ROOT / "viewport-entropy-toolkit_amd" / "csrc"
+    for f in sorted(csrc.glob("*.hpp")) + [csrc / "vet_api.hip"]:
+        h.update(f.read_bytes())
     return h.hexdigest()[:16]
 
 

@@ -17,8 +17,9 @@ DOMINANT = ("k_spatial_lut", "k_spatial_u_lds", "k_spatial_u", "k_spatial_w", "k
 
 def src_sha():
     h = hashlib.sha256()
-    for f in ("vet_kernels.hpp", "vet_api.hip"):
-        h.update((ROOT / "viewport-entropy-toolkit_amd" / "csrc" / f).read_bytes())
+    csrc = ROOT / "viewport-entropy-toolkit_amd" / "csrc"
+    for f in sorted(csrc.glob("*.hpp")) + [csrc / "vet_api.hip"]:
+        h.update(f.read_bytes())
     return h.hexdigest()[:16]
 
 

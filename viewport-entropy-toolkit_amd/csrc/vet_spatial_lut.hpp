@@ -1,0 +1,423 @@
+// vet_spatial_lut.hpp — k_spatial_lut: FoV-weighted spatial entropy through the direction weight table (the dominant kernel)
+// Part of the gfx950 device code of the viewport -> tile -> entropy path (see vet_kernels.hpp for the map).
+// Reference citations are relative to /root/reference/src/viewport_entropy_toolkit/.
+#pragma once
+#include "vet_weight_table.hpp"
+
+namespace vet {
+
+// ------------------------------------------------------------------------------------------
+// Row walk shared by the table kernels: the workgroup adds the ELL rows of the frame's distinct
+// directions into the LDS histogram hrow.  frows[j] = row << 12 | multiplicity (DEDUP) or the row
+// (multiplicity 1); fmeta[j] = the row's meta word.  A group of GS = 2^gs_log2 lanes walks one
+// row; UN rows per group are in flight; rows are zero padded, so a group walks to the longest of
+// its UN rows only.
+// ------------------------------------------------------------------------------------------
+
+constexpr int ROW_BITS = 19;
+constexpr uint32_t ROW_MASK = (1u << ROW_BITS) - 1;
+
+// FPT: FP table — entries are FP32 weights (relative precision 2^-24 each: |dH|/H <= 1.2e-7 for every frame, whatever the
+// weights' dynamic range), scaled by 2^E of their row; the histogram is FP64 (ds_add_f64) in true units.
+template <int UN, bool INTERLEAVED, bool DEDUP, bool FPT>
+__device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t* fmeta, int nu,
+                                          unsigned long long* hrow, int n,
+                                          const uint32_t* __restrict__ tab_w, const uint16_t* __restrict__ tab_i,
+                                          int stride, int gs_log2_rt, uint32_t zero_row) {
+    // Every lane takes one 4-slot chunk per block: one 16-byte load of weights, one 8-byte load of
+    // tiles (stride is a multiple of the block, so chunks are 16 / 8 byte aligned), then four
+    // unconditional ds_add_u64 of entry * (multiplicity << row shift): padding slots and idle lanes
+    // (which walk the all-zero row) add 0 to distinct tiles — no predicates around the adds.
+    const int NW = blockDim.x >> 6, lane = lane_id(), wv = wave_id();
+    const int gs_log2 = INTERLEAVED ? 4 : gs_log2_rt;       // class-dealt rows are 16-lane rows (ensure_wtab)
+    const int GS = 1 << gs_log2, UPW = WAVE >> gs_log2;
+    const int sub = lane >> gs_log2, sl = lane & (GS - 1);
+    const int step = NW * UPW;
+    // the lane's chunk of block eb holds entries eb + 4*sl + {0..3} (plain block) or eb + sl + GS*{0..3} (class-dealt
+    // block: every block with at least 3/4 of its slots in use): it has work while eb < len - cut
+    const int cut = INTERLEAVED ? min(4 * sl, 3 * GS - 1) : 4 * sl;
+    for (int j0 = wv * UPW; j0 < nu; j0 += UN * step) {
+        uint32_t row[UN];                 // entry offsets: a table holds fewer than 2^32 entries (ensure_wtab)
+        int lim[UN], sgn[UN];
+        char* hb[UN];
+        uint32_t mult[UN];
+        double scale[UN];
+        int longest = 0;
+#pragma unroll
+        for (int k = 0; k < UN; ++k) {
+            const int j = j0 + k * step + sub;
+            const bool on = j < nu;
+            const uint32_t pk = on ? frows[j] : 0u, m = on ? fmeta[j] : 0u;
+            const uint32_t key = DEDUP ? pk >> 12 : pk;
+            // a mirrored direction (x,-y,-z) walks its partner's row into the mirrored tiles n-1-t
+            const bool flip = ((DEDUP ? key >> ROW_BITS : key >> 31) & 1u) != 0u;
+            const uint32_t rid = DEDUP ? key & ROW_MASK : key & 0x7FFFFFFFu;
+            row[k] = on ? rid * (uint32_t)stride : zero_row;
+            const int len = (int)(m & 0xFFFFu);
+            lim[k] = len - cut;
+            const uint32_t cnt = DEDUP ? pk & 0xFFFu : (on ? 1u : 0u);
+            mult[k] = FPT ? cnt : cnt << ((m >> 16) & 0xFFFu);
+            if (FPT) scale[k] = ldexp((double)cnt, -(int)((m >> 16) & 0xFFFu));
+            sgn[k] = flip ? -8 : 8;
+            hb[k] = (char*)hrow + (flip ? (n - 1) * 8 : 0);
+            longest = max(longest, len);
+        }
+        for (int eb = 0; eb < longest; eb += 4 * GS) {
+            // a row that has ended reads the all-zero row (same slots, one hot line) instead of its own padding
+            // lines: the gather is bound by cache lines touched (TA/TD busy)
+            uint32_t r[UN];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                const bool on = eb < lim[k];
+                r[k] = (on ? row[k] : zero_row) + (uint32_t)(eb + 4 * sl);
+                any = any || on;
+            }
+            if (!any) continue;
+            uint4 w[UN];
+            ushort4 t[UN];
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                w[k] = *(const uint4*)(tab_w + r[k]);
+                t[k] = *(const ushort4*)(tab_i + r[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                if (FPT) {
+                    atomicAdd((double*)(hb[k] + (int)t[k].x * sgn[k]), (double)__uint_as_float(w[k].x) * scale[k]);
+                    atomicAdd((double*)(hb[k] + (int)t[k].y * sgn[k]), (double)__uint_as_float(w[k].y) * scale[k]);
+                    atomicAdd((double*)(hb[k] + (int)t[k].z * sgn[k]), (double)__uint_as_float(w[k].z) * scale[k]);
+                    atomicAdd((double*)(hb[k] + (int)t[k].w * sgn[k]), (double)__uint_as_float(w[k].w) * scale[k]);
+                } else {
+                    atomicAdd((unsigned long long*)(hb[k] + (int)t[k].x * sgn[k]), (unsigned long long)w[k].x * mult[k]);
+                    atomicAdd((unsigned long long*)(hb[k] + (int)t[k].y * sgn[k]), (unsigned long long)w[k].y * mult[k]);
+                    atomicAdd((unsigned long long*)(hb[k] + (int)t[k].z * sgn[k]), (unsigned long long)w[k].z * mult[k]);
+                    atomicAdd((unsigned long long*)(hb[k] + (int)t[k].w * sgn[k]), (unsigned long long)w[k].w * mult[k]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_spatial_lut — compute_spatial_entropy (entropy_utils.py:147-211), FoV-weighted mode, through
+// the direction weight table.  FPW frames per workgroup.
+// LDS:  hist u64 [FPW][n_sum]  per-frame tile weight sums, units of 2^-(32+TAB_X)
+//       hash u32 [FPW][HS]     DEDUP: open-addressing set of the frame's rows, slot = row << 12 | count;
+//                              shares the histogram's space (the set is compacted before the first add)
+//                              unless the users arrive in several chunks
+//       rows u32 [FPW][UC]     the frame's distinct rows (slot words), or one row per present user
+//       meta u32 [FPW][UC]     their meta words in the lattice being gathered
+//       cnt  i32 [FPW] rows in the chunk, [FPW] users present in the frame
+// Prologue: sample -> direction id -> canonical row (alias: directions with the same Vector — the pole
+// row, the -180 / -90 remaps — share one row) -> set insert.  Users looking in exactly the same
+// direction cost one row walk with a multiplicity instead of one each: 1024 users are ~710 distinct
+// rows on the random-walk workload, ~180 on a clustered audience.
+// A group of GS = 2^gs_log2 lanes walks one row (16-byte weight + 8-byte tile loads) and adds
+// entry * multiplicity into the frame histogram with ds_add_u64; a wave serves 64/GS rows at once and
+// two such steps are issued back to back to keep more loads in flight.
+// ------------------------------------------------------------------------------------------
+constexpr int MAX_LATTICES = 8;
+constexpr unsigned DEDUP_MAX_DIRS = (1u << 19) - 1;      // set key = row (19 bits) | mirror flag; slot = key << 12 | count
+
+struct LutLattice {
+    const uint32_t* tab_w;
+    const uint16_t* tab_i;
+    const uint32_t* tab_meta;
+    int stride, gs_log2, n, interleaved;
+    double hmax;
+};
+
+// One video of a batched launch (vet_spatial_entropy_batch): many short videos share one grid,
+// workgroups [block0, block0 + ceil(T / FPW)) belong to the video.
+struct VideoDesc {
+    const double* mu;
+    const double* mv;
+    int U, T;
+    double* entropy;
+    int32_t* assign;
+    int32_t* present;
+    int FPW, UC, block0, pad_;
+};
+
+struct LutParams {
+    const VideoDesc* videos;      // null: single video described by the fields below
+    int n_videos;
+    SampleSrc src;
+    int U, T;
+    const uint16_t* nearest;      // lattice 0 (assign)
+    const uint32_t* alias;        // [n_dirs] direction id -> canonical row | mirrored << 31
+    const uint2* dirrec;          // [n_dirs] DEDUP: alias, nearest tile and lattice-0 meta in one 8-byte record (k_dirrec)
+    int rec_meta;                 // the record's meta word is that of this launch's first lattice
+    int K;                        // lattices handled by this launch (<= MAX_LATTICES)
+    int n_sum;                    // sum of n over the K lattices
+    LutLattice lat[MAX_LATTICES];
+    double* entropy;              // [T] mean over the K lattices, summed in order
+    int32_t* assign;
+    double* weights;              // lattice 0
+    int32_t* present;
+    int32_t* status;
+    int FPW, UC;
+};
+
+// hash slots per frame: power of two >= 2 * UC, at least one wave's worth
+__host__ __device__ __forceinline__ int lut_hash_slots(int UC) {
+    int hs = 64;
+    while (hs < 2 * UC) hs <<= 1;
+    return hs;
+}
+// LDS bytes of a workgroup; the kernel and the host must agree
+__host__ __device__ __forceinline__ size_t lut_lds_bytes(int U, int UC, int FPW, int n_sum, bool dedup) {
+    const size_t hist = (size_t)FPW * n_sum * 8, hash = dedup ? (size_t)FPW * lut_hash_slots(UC) * 4 : 0;
+    const size_t a = (dedup && U <= UC) ? (hist > hash ? hist : hash) : hist + hash;
+    return ((a + 15) & ~(size_t)15) + (size_t)FPW * UC * 8 + (size_t)2 * FPW * 4 + 64;
+}
+
+// All K lattices of the plan in one launch: the samples are read once, every row is gathered into K
+// histograms, and avg_entropy = (e_0 + ... + e_{K-1}) / K is formed in lattice order as the
+// reference does (spatial_entropy.py:142-156) — no per-lattice pass, no finalize.
+// IL: some lattice of the plan has interleaved rows (otherwise only the plain walk is compiled in).
+// OCC8: compiled for 8 workgroups of 256 threads per CU (64 VGPRs) instead of 7 (68-70 VGPRs): measured
+// 2 % (random walk) to 6.5 % (clustered) faster on single-lattice plans and 7 % on batches of short
+// videos, but 2-4 % slower on one multi-lattice video (profiles/r01/v6_table_occupancy.log).
+// DEDUP: per-frame set of distinct rows with multiplicities (direction tables of < 2^20 rows).
+template <bool FROM_IDS, int UN, bool IL, bool OCC8, bool DEDUP, bool FPT>
+__global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // the video this workgroup works on: the launch's only one, or one of a batch
+    SampleSrc src = p.src;
+    int U = p.U, T = p.T, FPW = p.FPW, UC = p.UC;
+    double* entropy = p.entropy;
+    int32_t* assign = p.assign;
+    int32_t* present = p.present;
+    double* weights = p.weights;
+    long blk = blockIdx.x;
+    if (p.videos) {
+        int lo = 0, hi = p.n_videos - 1;                   // last video with block0 <= blockIdx.x
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (p.videos[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        const VideoDesc& d = p.videos[lo];
+        src.mu = d.mu; src.mv = d.mv;
+        U = d.U; T = d.T; FPW = d.FPW; UC = d.UC;
+        entropy = d.entropy; assign = d.assign; present = d.present; weights = nullptr;
+        blk -= d.block0;
+    }
+    const int HS = DEDUP ? lut_hash_slots(UC) : 0;
+    const bool overlay = DEDUP && U <= UC;                                       // one chunk: set and histogram share space
+    const size_t hist_bytes = (size_t)FPW * p.n_sum * 8, hash_bytes = (size_t)FPW * HS * 4;
+    const size_t a_bytes = overlay ? (hist_bytes > hash_bytes ? hist_bytes : hash_bytes) : hist_bytes + hash_bytes;
+    unsigned long long* hist = (unsigned long long*)smem;                        // [FPW][n_sum]
+    uint32_t* hash = (uint32_t*)(smem + (overlay ? 0 : hist_bytes));             // [FPW][HS]
+    uint32_t* rows = (uint32_t*)(smem + ((a_bytes + 15) & ~(size_t)15));         // [FPW][UC]
+    uint32_t* meta = rows + (size_t)FPW * UC;                                    // [FPW][UC]
+    int* cnt_chunk = (int*)(meta + (size_t)FPW * UC);                            // [FPW]
+    int* cnt_frame = cnt_chunk + FPW;                                            // [FPW]
+    const int NW = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const long f0 = blk * FPW;
+    const int nf = (int)min((long)FPW, (long)T - f0);
+    if (!overlay)
+        for (int i = tid; i < FPW * p.n_sum; i += blockDim.x) hist[i] = 0ull;
+    for (int i = tid; i < 2 * FPW; i += blockDim.x) cnt_chunk[i] = 0;
+    bool bad = false;
+    const int hs_shift = 32 - (31 - __clz(HS | 1));
+    for (int u0 = 0; u0 < U; u0 += UC) {
+        const int uc = min(UC, U - u0);
+        __syncthreads();
+        for (int i = tid; i < FPW; i += blockDim.x) cnt_chunk[i] = 0;
+        if (DEDUP)
+            for (int i = tid; i < FPW * HS; i += blockDim.x) hash[i] = EMPTY_KEY;
+        __syncthreads();
+        // SPT samples per thread and round: all sample loads first, then the table gathers, then the LDS set
+        // inserts — three waves of independent requests instead of SPT dependent chains
+        constexpr int SPT = 4;
+        const int total = nf * uc;
+        for (int i0 = tid; i0 < total; i0 += SPT * (int)blockDim.x) {
+            int id[SPT], fls[SPT];
+            long idxs[SPT];
+            if (FROM_IDS) {
+#pragma unroll
+                for (int k = 0; k < SPT; ++k) {
+                    const int i = i0 + k * (int)blockDim.x;
+                    fls[k] = i / uc;
+                    idxs[k] = (f0 + fls[k]) * (long)U + u0 + (i - fls[k] * uc);
+                    id[k] = -1;
+                    if (i < total) {
+                        const int v = src.ids[idxs[k]];
+                        if (v >= src.n_dirs) bad = true; else if (v >= 0) id[k] = v;
+                    }
+                }
+            } else {
+                double a[SPT], b[SPT];
+#pragma unroll
+                for (int k = 0; k < SPT; ++k) {
+                    const int i = i0 + k * (int)blockDim.x;
+                    fls[k] = i / uc;
+                    idxs[k] = (f0 + fls[k]) * (long)U + u0 + (i - fls[k] * uc);
+                    a[k] = b[k] = __builtin_nan("");
+                    if (i < total) {
+                        a[k] = __builtin_nontemporal_load(src.mu + idxs[k]);
+                        b[k] = __builtin_nontemporal_load(src.mv + idxs[k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < SPT; ++k) id[k] = grid_dir(a[k], b[k], src.W, src.H, bad);
+            }
+            uint32_t row[SPT], m0[SPT];
+            int near[SPT];
+#pragma unroll
+            for (int k = 0; k < SPT; ++k) {
+                row[k] = 0u; near[k] = -1; m0[k] = 0u;
+                if (id[k] >= 0) {
+                    if (DEDUP) {
+                        const uint2 rec = p.dirrec[id[k]];
+                        row[k] = (rec.x & ROW_MASK) | ((rec.x >> 31) << ROW_BITS);
+                        near[k] = (int)(((rec.x >> ROW_BITS) & 0xFFFu) | ((rec.y >> 28) << 12));
+                        m0[k] = rec.y & 0xFFFFFFFu;
+                    } else if (p.dirrec) {                      // small frames: no set, but the fused record
+                        const uint2 rec = p.dirrec[id[k]];
+                        row[k] = (rec.x & ROW_MASK) | (rec.x & 0x80000000u);
+                        near[k] = (int)(((rec.x >> ROW_BITS) & 0xFFFu) | ((rec.y >> 28) << 12));
+                        m0[k] = rec.y & 0xFFFFFFFu;
+                    } else {
+                        row[k] = p.alias[id[k]];                // canonical row | mirrored << 31
+                        if (assign) near[k] = (int)p.nearest[id[k]];
+                    }
+                }
+            }
+            if (assign) {
+#pragma unroll
+                for (int k = 0; k < SPT; ++k)
+                    if (i0 + k * (int)blockDim.x < total) __builtin_nontemporal_store(near[k], assign + idxs[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < SPT; ++k) {
+                const bool valid = id[k] >= 0;
+                const int fl = fls[k];
+                // users present per frame / new rows per frame: one LDS atomic per wave where the wave's
+                // samples belong to one frame (always when the user count is a multiple of 64)
+                const int fl0 = __builtin_amdgcn_readfirstlane(fl);
+                const bool uniform = __ballot(fl != fl0) == 0ull;
+                bool won = false;
+                unsigned h = 0;
+                if (DEDUP) {
+                    if (valid) {
+                        uint32_t* tab = hash + (size_t)fl * HS;
+                        h = (row[k] * 2654435761u) >> hs_shift;
+                        for (;;) {
+                            unsigned cur = tab[h];
+                            if (cur == EMPTY_KEY) {
+                                cur = atomicCAS(&tab[h], EMPTY_KEY, (row[k] << 12) | 1u);
+                                if (cur == EMPTY_KEY) { won = true; break; }
+                            }
+                            if ((cur >> 12) == row[k]) { atomicAdd(&tab[h], 1u); break; }
+                            h = (h + 1) & (unsigned)(HS - 1);
+                        }
+                    }
+                } else {
+                    won = valid;
+                }
+                const unsigned long long mv_ = __ballot(valid), mw = __ballot(won);
+                if (uniform) {
+                    int base = 0;
+                    if (lane == 0) {
+                        if (mv_) atomicAdd(&cnt_frame[fl0], (int)__popcll(mv_));
+                        if (mw) base = atomicAdd(&cnt_chunk[fl0], (int)__popcll(mw));
+                    }
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (won) {
+                        const size_t pos = (size_t)fl0 * UC + base + below(mw);
+                        rows[pos] = DEDUP ? h : row[k];
+                        meta[pos] = m0[k];
+                    }
+                } else {
+                    if (valid) atomicAdd(&cnt_frame[fl], 1);
+                    if (won) {
+                        const size_t pos = (size_t)fl * UC + atomicAdd(&cnt_chunk[fl], 1);
+                        rows[pos] = DEDUP ? h : row[k];
+                        meta[pos] = m0[k];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (DEDUP) {
+            // slot numbers -> slot words (row << 12 | multiplicity)
+            for (int i = tid; i < nf * UC; i += blockDim.x) {
+                const int fl = i / UC, j = i - fl * UC;
+                if (j < cnt_chunk[fl]) rows[i] = hash[(size_t)fl * HS + rows[i]];
+            }
+            if (overlay) {
+                __syncthreads();
+                for (int i = tid; i < FPW * p.n_sum; i += blockDim.x) hist[i] = 0ull;
+            }
+        }
+        int hoff = 0;
+        for (int k = 0; k < p.K; ++k) {
+            const LutLattice& L = p.lat[k];
+            // meta words (length, shift) of this lattice for every staged row: one parallel gather, so the
+            // walk below has no dependent global load in front of its row loads
+            if (k) __syncthreads();
+            if (!(k == 0 && p.rec_meta && (DEDUP || p.dirrec)))
+                for (int i = tid; i < nf * UC; i += blockDim.x) {
+                    const int fl = i / UC, j = i - fl * UC;
+                    if (j < cnt_chunk[fl]) meta[i] = L.tab_meta[DEDUP ? (rows[i] >> 12) & ROW_MASK : rows[i] & 0x7FFFFFFFu];
+                }
+            __syncthreads();
+            for (int fl = 0; fl < nf; ++fl)
+                if (IL && L.interleaved)
+                    walk_rows<UN, true, DEDUP, FPT>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
+                                               hist + (size_t)fl * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
+                                               (uint32_t)src.n_dirs * (uint32_t)L.stride);
+                else
+                    walk_rows<UN, false, DEDUP, FPT>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
+                                                hist + (size_t)fl * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
+                                                (uint32_t)src.n_dirs * (uint32_t)L.stride);
+            hoff += L.n;
+        }
+    }
+    __syncthreads();
+    // entropy (entropy_utils.py:194-211, weighted: normaliser log2 n); wave w takes frames w, w+NW, ...
+    const double inv_unit = 1.0 / (4294967296.0 * (double)(1u << TAB_X));
+    for (int fl = wv; fl < nf; fl += NW) {
+        const unsigned long long* hrow = hist + (size_t)fl * p.n_sum;
+        double total_entropy = 0.0;
+        for (int k = 0; k < p.K; ++k) {
+            const int n = p.lat[k].n;
+            // total weight can exceed 64 bits of fixed point: summed in FP64, fixed lane order + butterfly
+            double totd = 0.0;
+            for (int t = lane; t < n; t += WAVE) totd += FPT ? __longlong_as_double((long long)hrow[t]) : (double)hrow[t];
+            totd = wave_sum(totd);
+            double h = 0.0;
+            for (int t = lane; t < n; t += WAVE) {
+                const double v = FPT ? __longlong_as_double((long long)hrow[t]) : (double)hrow[t];
+                if (v != 0.0) {
+                    const double q = v / totd;
+                    h -= q * log2(q);
+                }
+                if (k == 0 && weights) __builtin_nontemporal_store(FPT ? v : v * inv_unit, weights + (f0 + fl) * (long)n + t);
+            }
+            h = wave_sum(h);
+            total_entropy += h / p.lat[k].hmax;
+            hrow += n;
+        }
+        if (lane == 0) {
+            const int np = cnt_frame[fl];
+            double e = total_entropy / (double)p.K;
+            if (np == 0) {
+                e = __builtin_nan("");
+                if (p.status) atomicAdd(&p.status[1], 1);
+            }
+            entropy[f0 + fl] = e;
+            if (present) present[f0 + fl] = np;
+        }
+    }
+    if (p.status) {
+        const unsigned long long anybad = __ballot(bad);
+        if (anybad && lane == 0) atomicAdd(&p.status[0], (int)__popcll(anybad));
+    }
+}
+
+}  // namespace vet

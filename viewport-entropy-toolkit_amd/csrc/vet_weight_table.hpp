@@ -1,0 +1,256 @@
+// vet_weight_table.hpp — the direction weight table: k_row_stats (error bounds), k_wtab (ELL rows), k_dirrec (per-direction records)
+// Part of the gfx950 device code of the viewport -> tile -> entropy path (see vet_kernels.hpp for the map).
+// Reference citations are relative to /root/reference/src/viewport_entropy_toolkit/.
+#pragma once
+#include "vet_weights.hpp"
+
+namespace vet {
+
+// ------------------------------------------------------------------------------------------
+// Direction weight table (ELL).  The sample domain is discrete — (W+1)(H+1) pixel directions —
+// and the weight of a (direction, tile) pair depends on nothing else, so for videos with more
+// samples than directions the rows  {(tile, w)} : w > 0  are evaluated once per plan (exact
+// ocml acos / pow, any fov and power) and the per-frame histogram becomes a gather of rows:
+//   hist[t] += count(d) * w(d, t)   for the distinct directions d of the frame's users and the ~n/4
+//   tiles in d's FoV.
+// Row d lives at w[d*stride .. ] (u32 mantissas) and idx[d*stride ..] (u16 tile), sorted by tile,
+// zero padded.  Block floating point per ROW: with e = ceil(log2(largest weight of the row)) clamped
+// to [-TAB_X, 0], entry = rint(w * 2^(32 - e)) (saturating), and the gather adds
+// entry * (count << (TAB_X + e)) to a 64-bit histogram in units of 2^-(32 + TAB_X): a row whose
+// weights are all small (narrow FoV, large power) keeps 32 significant bits below its own maximum
+// instead of below 1.0.  meta[d] = entries in use | (TAB_X + e) << 16.
+//
+// k_row_stats (once per lattice, before the first weighted run) evaluates every row exactly and
+// decides whether integer histograms are inside the 1e-6 relative contract for EVERY possible frame:
+// with absolute step q_d on the entries of row d, k_d entries, exact row sum S_d and row entropy H_d,
+//   |dH| <= 36.5 * sum_i c_i k_i q_i / S   and   H >= sum_i c_i S_i H_i / S   (entropy is concave)
+// for a frame made of rows i with multiplicities c_i, hence  |dH| / H <= max_d 36.5 q_d k_d / (S_d H_d).
+// Plans where that bound exceeds 1e-7 (rows with a single tile in the FoV, weights spanning many
+// orders of magnitude) take the FP64 formulation (k_spatial_w<PRECISE>) instead.
+// k_wtab<false> finds the longest row (conservative cone test), k_wtab<true> fills the rows.
+// One wave per direction; lane = tile.
+// ------------------------------------------------------------------------------------------
+constexpr int TAB_X = 16;       // histogram unit 2^-(32+TAB_X): sums of < 2^16 weights <= 1 fit 64 bits
+
+struct StatsParams {
+    const double* dir_unit;
+    long D;
+    const double* tiles;
+    int n;
+    double cos_cull;
+    WeightCfg wc;
+    uint8_t* row_s;             // [D+1] TAB_X + e per row (row D = the all-zero row)
+    uint16_t* row_e;            // [D+1] E = -(binary exponent of the row's largest weight), unclamped (FP table)
+    unsigned long long* crit;   // [2] bit patterns of non-negative doubles (atomicMax):
+                                //   [0] max_d 36.5 q_d k_d / (S_d H_d)   with the table's q_d = 2^(e_d - 33)
+                                //   [1] max_d 36.5 k_d / (S_d H_d)       (times the sweep's step, 2^(shift-53))
+};
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+__global__ void k_row_stats(const StatsParams p) {
+    const int lane = lane_id();
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    double worst_tab = 0.0, worst_sweep = 0.0;
+    for (long d = wave; d < p.D; d += nwaves) {
+        const double dx = p.dir_unit[3 * d], dy = p.dir_unit[3 * d + 1], dz = p.dir_unit[3 * d + 2];
+        double S = 0.0, L = 0.0, mx = 0.0;
+        int k = 0;
+        for (int t0 = 0; t0 < p.n; t0 += WAVE) {
+            const int t = t0 + lane;
+            const bool valid = t < p.n;
+            const int ts = valid ? t : 0;
+            const double c = fma(dz, p.tiles[3 * ts + 2], fma(dy, p.tiles[3 * ts + 1], dx * p.tiles[3 * ts]));
+            if (valid && c > p.cos_cull) {
+                const double wt = fov_weight_exact(c, p.wc);
+                if (wt > 0.0) { ++k; S += wt; L += wt * log2(wt); mx = fmax(mx, wt); }
+            }
+        }
+        k = wave_sum(k); S = wave_sum(S); L = wave_sum(L); mx = wave_max(mx);
+        int e = 0;
+        if (mx > 0.0) (void)frexp(mx, &e);                  // mx <= 2^e
+        if (lane == 0) p.row_e[d] = (uint16_t)min(2047, max(0, -e));
+        e = min(0, max(-TAB_X, e));
+        if (lane == 0) p.row_s[d] = (uint8_t)(TAB_X + e);
+        if (k >= 1) {
+            // row entropy -sum (w/S) log2(w/S) = log2 S - (sum w log2 w) / S; its own rounding error (~1e-15)
+            // only matters where the bound is hopeless anyway
+            const double H = k >= 2 ? fmax(log2(S) - L / S, 0.0) : 0.0;
+            const double base = H > 0.0 ? 36.5 * (double)k / (S * H) : __builtin_inf();
+            worst_tab = fmax(worst_tab, base * ldexp(1.0, e - 33));
+            worst_sweep = fmax(worst_sweep, base);
+        }
+    }
+    if (lane == 0) {
+        if (p.row_s && wave == 0) { p.row_s[p.D] = (uint8_t)TAB_X; p.row_e[p.D] = 0; }
+        if (worst_tab > 0.0) atomicMax(&p.crit[0], (unsigned long long)__double_as_longlong(worst_tab));
+        if (worst_sweep > 0.0) atomicMax(&p.crit[1], (unsigned long long)__double_as_longlong(worst_sweep));
+    }
+}
+
+struct WtabParams {
+    const double* dir_unit;
+    long D;
+    const double* tiles;
+    int n;
+    double cos_cull;
+    WeightCfg wc;
+    int stride;
+    uint32_t* w;
+    uint16_t* idx;
+    uint32_t* meta;     // [D+1] entries in use per row | row shift << 16
+    const uint8_t* row_s;
+    const uint16_t* row_e;
+    int fp;             // FP table: entries are FP32 weights scaled by 2^E of their row, meta field = E
+    int* maxcount;
+    int gs_log2;        // >= 0: well-filled blocks dealt over the 2^gs_log2 lanes of a gather group
+};
+
+// Row layout.  The gather gives every lane of a group of GS = 2^gs_log2 lanes one 16-byte chunk
+// (4 slots = 4 components) per block of B = 4*GS entries, and component k of all lanes is added by
+// ONE ds_add_u64 instruction.  Measured on MI355X (tools/lds_atomic_probe.hip): the LDS services
+// that instruction in four groups of 16 contiguous lanes, one cycle per group when the 16 slots
+// differ mod 16 (8-byte slots: bank pair = slot mod 16), one more cycle per extra slot of a class,
+// two per extra lane on the same address; lanes of different groups never conflict.  With 16-lane
+// gather groups a hardware group is exactly one row, so the cost is decided by the row layout:
+// tile-sorted entries dealt 4 per lane put tiles ~14 apart into one instruction (mostly one or two
+// classes: ~4 cycles per group).  So in a block that is at least 3/4 full (B = 64, GS = 16) the
+// entries are DEALT BY CLASS: the r-th entry of a class (tile mod 16) goes to component r mod 4,
+// inside a component to the next free lane; what does not fit (a component's 17th entry) and the
+// block's padding fill the remaining (lane, component) places, padding on tiles of classes the
+// component does not use.  Typical result: one entry per class and component = conflict-free.
+// Emptier blocks (short rows of small lattices, row tails) keep the plain order, where only the
+// first lanes of the group have work.
+__device__ __forceinline__ bool block_interleaved(int len, int eb, int gs_log2) {
+    const int B = 4 << gs_log2;
+    return gs_log2 >= 0 && 4 * min(B, len - eb) >= 3 * B;
+}
+__device__ __forceinline__ int below(unsigned long long m) {      // set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+template <bool FILL>
+__global__ void k_wtab(const WtabParams p) {
+    const int lane = lane_id();
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    int longest = 0;
+    for (long d = wave; d < p.D; d += nwaves) {
+        const double dx = p.dir_unit[3 * d], dy = p.dir_unit[3 * d + 1], dz = p.dir_unit[3 * d + 2];
+        int count = 0;
+        const int row_shift = FILL ? (p.fp ? (int)p.row_e[d] : (int)p.row_s[d]) : 0;
+        const double scale = p.fp ? ldexp(1.0, row_shift) : ldexp(1.0, 32 + TAB_X - row_shift);        // 2^E / 2^(32 - e)
+        for (int t0 = 0; t0 < p.n; t0 += WAVE) {
+            const int t = t0 + lane;
+            const bool valid = t < p.n;
+            const int ts = valid ? t : 0;
+            const double c = fma(dz, p.tiles[3 * ts + 2], fma(dy, p.tiles[3 * ts + 1], dx * p.tiles[3 * ts]));
+            bool hit = valid && (c > p.cos_cull);
+            unsigned w32 = 0u;
+            if (FILL) {
+                if (hit) {
+                    const double wt = fov_weight_exact(c, p.wc);
+                    w32 = p.fp ? __float_as_uint((float)(wt * scale)) : (unsigned)fmin(rint(wt * scale), 4294967295.0);
+                }
+                hit = w32 != 0u;
+            }
+            const unsigned long long mask = __ballot(hit);
+            if (FILL && hit) {
+                const int pos = count + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                        __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                p.w[d * p.stride + pos] = w32;
+                p.idx[d * p.stride + pos] = (uint16_t)t;
+            }
+            count += __popcll(mask);
+        }
+        if (FILL) {
+            // padding: weight 0 on distinct tiles, so the gather can add every slot unconditionally
+            // without piling zero adds onto one LDS address
+            for (int pos = count + lane; pos < p.stride; pos += WAVE) {
+                p.w[d * p.stride + pos] = 0u;
+                p.idx[d * p.stride + pos] = (uint16_t)(pos % p.n);
+            }
+            if (lane == 0) p.meta[d] = (uint32_t)count | ((uint32_t)row_shift << 16);
+            // well-filled blocks of 16-lane rows: deal the entries by class (one wave pass per block, lane =
+            // sorted entry; the loads of all lanes have returned before the first store issues)
+            if (p.gs_log2 == 4) {
+                for (int eb = 0; eb < count; eb += WAVE) {
+                    if (!block_interleaved(count, eb, p.gs_log2)) continue;
+                    __threadfence_block();
+                    const bool real = eb + lane < count;
+                    uint32_t wv = 0; uint16_t iv = 0;
+                    if (real) { wv = p.w[d * p.stride + eb + lane]; iv = p.idx[d * p.stride + eb + lane]; }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const int cls = iv & 15;
+                    int r = 0;                                   // rank among the entries of the same class
+                    for (int c = 0; c < 16; ++c) {
+                        const unsigned long long m = __ballot(real && cls == c);
+                        if (real && cls == c) r = below(m);
+                    }
+                    int comp = r & 3, q = 0, used[4], freeb[5];
+                    for (int k = 0; k < 4; ++k) {                // lane inside the component, 16 places each
+                        const unsigned long long m = __ballot(real && comp == k);
+                        if (real && comp == k) q = below(m);
+                        used[k] = min(16, (int)__popcll(m));
+                    }
+                    const bool placed = real && q < 16;
+                    unsigned usedmask[4];                        // classes present in each component
+                    for (int k = 0; k < 4; ++k) {
+                        usedmask[k] = 0;
+                        for (int c = 0; c < 16; ++c)
+                            if (__ballot(placed && comp == k && cls == c)) usedmask[k] |= 1u << c;
+                    }
+                    freeb[0] = 0;
+                    for (int k = 0; k < 4; ++k) freeb[k + 1] = freeb[k] + 16 - used[k];
+                    if (!placed) {                               // leftovers take the free places in order
+                        const int j = below(__ballot(!placed));
+                        int k = 0;
+                        while (k < 3 && j >= freeb[k + 1]) ++k;
+                        const int jj = j - freeb[k];
+                        comp = k; q = used[k] + jj;
+                        if (!real) {                             // padding: jj-th class the component lacks
+                            int seen = 0, c = 0;
+                            for (; c < 15; ++c) {
+                                if (!((usedmask[k] >> c) & 1u)) { if (seen == jj) break; ++seen; }
+                            }
+                            iv = (uint16_t)c;                    // tile c has class c (n > 16 for 16-lane rows)
+                        }
+                    }
+                    p.w[d * p.stride + eb + q * 4 + comp] = wv;
+                    p.idx[d * p.stride + eb + q * 4 + comp] = iv;
+                }
+            }
+        }
+        longest = max(longest, count);
+    }
+    // a plain read first: the maximum only grows, so most waves find theirs already covered and skip
+    // the same-address atomic (2048 of them cost ~100 us)
+    if (!FILL && lane == 0 && longest > *(volatile int*)p.maxcount) atomicMax(p.maxcount, longest);
+    if (FILL && wave == 0) {            // row D: the all-zero row idle lanes of the gather point at
+        for (int pos = lane; pos < p.stride; pos += WAVE) {
+            p.w[p.D * p.stride + pos] = 0u;
+            // lane l of a 16-lane group adds its zeros to tile l: 16 classes, no conflict
+            p.idx[p.D * p.stride + pos] = (uint16_t)(p.gs_log2 == 4 ? (pos >> 2) & 15 : pos % p.n);
+        }
+        if (lane == 0) p.meta[p.D] = p.fp ? 0u : (uint32_t)TAB_X << 16;
+    }
+}
+
+
+// Per-direction record of the table kernel's prologue: one 8-byte gather per sample instead of three
+// (alias, nearest tile, row meta):  x = row (19 bits) | nearest tile bits 0..11 << 19 | mirrored << 31
+//                                     y = meta of the row in lattice 0 (28 bits) | nearest tile bits 12..15 << 28
+__global__ void k_dirrec(const uint32_t* __restrict__ alias, const uint16_t* __restrict__ nearest,
+                         const uint32_t* __restrict__ meta0, long D, uint2* __restrict__ rec) {
+    for (long d = blockIdx.x * (long)blockDim.x + threadIdx.x; d < D; d += (long)gridDim.x * blockDim.x) {
+        const uint32_t a = alias[d], near = nearest[d], row = a & 0x7FFFFu;
+        rec[d] = make_uint2(row | ((near & 0xFFFu) << 19) | (a & 0x80000000u), (meta0[row] & 0xFFFFFFFu) | ((near >> 12) << 28));
+    }
+}
+
+}  // namespace vet
