@@ -1,4 +1,4 @@
-"""world_size-2 gloo tests (CPU) of the multi-GPU plumbing: video sharding, the single gather of
+"""world_size-2, -3 and -8 gloo tests (CPU) of the multi-GPU plumbing: video sharding, the single gather of
 the entropy series, and frame sharding with a halo in transition mode.  The per-rank compute is
 the CPU oracle here (the product's compute is the HIP engine; on the GPU box bench.py drives it)."""
 import os
@@ -50,13 +50,15 @@ def _worker(rank, world, port, case, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["videos", "frames", "fixed"])
-def test_two_ranks_gloo(case):
+@pytest.mark.parametrize("case,world", [("videos", 2), ("frames", 2), ("fixed", 2),
+                                        # uneven shards: 5 videos / 40 rows over 3 ranks, 8 ranks with more ranks than videos
+                                        ("videos", 3), ("frames", 3), ("videos", 8), ("frames", 8)])
+def test_ranks_gloo(case, world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
