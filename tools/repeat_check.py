@@ -1,0 +1,50 @@
+"""Race hunt: the integer formulations and the transition kernel are order independent by construction, so repeated
+calls on the same input must agree bit for bit.  Runs each case many times and compares with the first result."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'viewport-entropy-toolkit_amd'))
+import numpy as np, torch
+from viewport_entropy_toolkit import _native, _quantiser
+import bench
+dev = torch.device('cuda', 0)
+eng = _native.Engine(0)
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+cases = [("spatial", 1024, 3000, [500], True, "random_walk"), ("spatial", 1024, 3000, [500], True, "clustered"),
+         ("spatial", 256, 2000, [50, 100, 200], True, "random_walk"), ("spatial", 64, 3000, [50, 100, 200], True, "random_walk"),
+         ("spatial", 1024, 3000, [500], False, "random_walk"), ("spatial", 300, 500, [20, 50, 100, 250, 1000], True, "uniform"),
+         ("transition", 512, 10000, [200], True, "random_walk"), ("transition", 512, 4000, [200], True, "clustered"),
+         ("transition", 300, 999, [200], True, "uniform"), ("transition", 1500, 300, [50], True, "random_walk"),
+         ("transition", 5000, 40, [50, 20], True, "random_walk")]
+t0 = time.perf_counter()
+for mode, U, T, tcs, weighted, kind in cases:
+    mu_h, mv_h = bench.synth_video(U, T, 77, 0, kind)
+    mu_h[::7, ::5] = np.nan; mv_h[::7, ::5] = np.nan
+    mu_h[:, 0] = 0.5; mv_h[:, 0] = 0.5
+    mu = torch.from_numpy(mu_h).to(dev); mv = torch.from_numpy(mv_h).to(dev)
+    R = T if mode == "spatial" else T - 1
+    ent = torch.empty(R, dtype=torch.float64, device=dev)
+    idx = torch.empty((T, U) if mode == "spatial" else (R, U, 2), dtype=torch.int32, device=dev)
+    st = torch.zeros(2, dtype=torch.int32, device=dev)
+    plan = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in tcs], 120.0, 2.0, weighted, 100, 200)
+    plan.set_table_policy(1)
+    s = torch.cuda.Stream(device=dev)
+    first = None
+    bad = 0
+    for r in range(reps):
+        ent.fill_(-1.0); idx.fill_(-7)
+        s.wait_stream(torch.cuda.current_stream())
+        if mode == "spatial":
+            plan.spatial_device(mu.data_ptr(), mv.data_ptr(), U, T, ent.data_ptr(), d_assign=idx.data_ptr(), d_status=st.data_ptr(), stream=s.cuda_stream)
+        else:
+            plan.transition_device(mu.data_ptr(), mv.data_ptr(), U, T, ent.data_ptr(), d_pairs=idx.data_ptr(), d_status=st.data_ptr(), stream=s.cuda_stream)
+        s.synchronize()
+        got = (ent.cpu().numpy().copy(), idx.cpu().numpy().copy())
+        if first is None:
+            first = got
+        elif not (np.array_equal(got[0], first[0], equal_nan=True) and np.array_equal(got[1], first[1])):
+            bad += 1
+    form = plan.last_formulation(0) if mode == "spatial" and weighted else "-"
+    print(f"{mode:10s} U={U:5d} T={T:6d} tcs={tcs} weighted={weighted} {kind:11s} form={form:7s} repeats={reps} mismatches={bad}", flush=True)
+    plan.close()
+    assert bad == 0
+print(f"all cases bit-identical over {reps} repeats ({time.perf_counter() - t0:.0f} s)")
