@@ -15,7 +15,8 @@ Fixtures:
   G4 spatial analyzer runs (config 1), G5 transition analyzer runs,
   G6 ingest edge cases, G7 per-direction weight rows, G8 dense transition
   frames (bucket quirk exercised), G9 operator-level edge cases, G10 naive lat/lon analyzer,
-  G11 tile boundary / area geometry of the Fibonacci tiling.
+  G11 tile boundary / area geometry of the Fibonacci tiling,
+  G12 FoV weights that underflow to 0.0 (large power_factor): NaN pattern and the 0.0-valued tile_weights keys.
 """
 
 from __future__ import annotations
@@ -560,6 +561,50 @@ def g11_geometry(vt):
     out["gc_p1"] = np.array([du.great_circle_intersection(a, b)[0] for a, b in zip(n1, n2)])
     np.savez_compressed(OUT / "g11_geometry.npz", **out)
 
+# ----------------------------------------------------------------------------
+def g12_underflow(vt):
+    """compute_spatial_entropy with power factors so large that in-FoV weights underflow to (sub)normal tiny values
+    or exactly 0.0: the reference keeps those tiles in its dict (entropy_utils.py:131-135) and 0 * log2(0) makes
+    the frame's entropy NaN (:195-198).  Eight-user and one-user frames on the 100 x 200 grid."""
+    from viewport_entropy_toolkit import Vector
+    from viewport_entropy_toolkit.utilities import generate_fibonacci_lattice, compute_spatial_entropy, EntropyConfig
+    import warnings
+    warnings.simplefilter("ignore")
+    grid = np.load(OUT / "g2_quantiser.npz")["vec_100x200"]
+    rng = np.random.default_rng(1212)
+    F8, F1, U = 20, 20, 8
+    px = rng.integers(0, 101, (F8 + F1, U))
+    py = np.clip(np.rint(100 + 45 * rng.standard_normal((F8 + F1, U))), 0, 200).astype(np.int64)
+    # half of the eight-user frames: a clustered audience (tiles shared between users with very different weights)
+    px[:F8 // 2] = (px[:F8 // 2, :1] + rng.integers(-6, 7, (F8 // 2, U))) % 101
+    py[:F8 // 2] = np.clip(py[:F8 // 2, :1] + rng.integers(-6, 7, (F8 // 2, U)), 0, 200)
+    px[F8:, 1:] = -1                     # one-user frames
+    py[F8:, 1:] = -1
+    out = {"px": px, "py": py}
+    for tc in (50, 500):
+        L = generate_fibonacci_lattice(tc)
+        idx = {v: i for i, v in enumerate(L)}
+        for fov in (120.0, 60.0):
+            for power in (50.0, 80.0, 100.0, 150.0, 200.0):
+                cfg = EntropyConfig(fov_angle=fov, power_factor=power)
+                ent = np.zeros(len(px))
+                hist = np.zeros((len(px), len(L)))
+                keys = np.zeros((len(px), len(L)), dtype=bool)
+                for f in range(len(px)):
+                    vd = {f"u{u}": Vector(*map(float, grid[py[f, u], px[f, u]])) for u in range(U) if px[f, u] >= 0}
+                    e, tw, _ = compute_spatial_entropy(vd, L, cfg)
+                    ent[f] = e
+                    for tv, w in tw.items():
+                        hist[f, idx[tv]] = w
+                        keys[f, idx[tv]] = True
+                tag = f"tc{tc}_fov{int(fov)}_p{int(power)}"
+                out[f"{tag}__entropy"] = ent
+                out[f"{tag}__hist"] = hist
+                out[f"{tag}__keys"] = keys
+                print("G12", tag, "nan frames (8 users, 1 user):", int(np.isnan(ent[:F8]).sum()), int(np.isnan(ent[F8:]).sum()),
+                      "zero-valued keys:", int((keys & (hist == 0)).sum()), "subnormal:", int(((hist > 0) & (hist < 2.3e-308)).sum()))
+    np.savez_compressed(OUT / "g12_underflow.npz", **out)
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -593,6 +638,8 @@ def main():
         g10_naive(vt, synth)
     if want("G11"):
         g11_geometry(vt)
+    if want("G12"):
+        g12_underflow(vt)
     if want("G4"):
         g4_spatial(vt, synth)
     if want("G5"):

@@ -101,7 +101,10 @@ int oracle_spatial(const double *mu, const double *mv, int T, int U, int W, int 
                     }
                 const double mx = (weighted || total_weight > n) ? max_entropy((double)n) : max_entropy(total_weight);
                 total_entropy += ent / mx;
-                if (k == 0 && out_weights0) memcpy(out_weights0 + (long)t * n, hist, sizeof(double) * n);
+                /* dense convention of the C-ABI: a dict key with the value 0.0 carries -0.0, no key +0.0 */
+                if (k == 0 && out_weights0)
+                    for (int j = 0; j < n; ++j)
+                        out_weights0[(long)t * n + j] = (touched[j] && hist[j] == 0.0) ? -0.0 : hist[j];
             }
             out_entropy[t] = total_entropy / K;
             if (frc) {

@@ -119,18 +119,23 @@ def nearest_tile(dirs: np.ndarray, tiles: np.ndarray, chunk: int = 8192) -> np.n
 
 
 def tile_weight_rows(dirs: np.ndarray, tiles: np.ndarray, fov_angle: float = 120.0,
-                     power_factor: float = 2.0, use_weight_distribution: bool = True) -> np.ndarray:
+                     power_factor: float = 2.0, use_weight_distribution: bool = True,
+                     return_keys: bool = False):
     """entropy_utils.py:108-144: [D, n] weight rows (0 where the reference has
-    no dict entry)."""
+    no dict entry).  ``return_keys``: also the [D, n] mask of the tiles that ARE
+    in the reference's dict — every tile with distance < max (:131-135), also
+    when ``(..) ** power_factor`` underflows to exactly 0.0."""
     d = angular_distances(dirs, tiles)
     if use_weight_distribution:
         mx = np.radians(fov_angle / 2.0)
-        with np.errstate(invalid="ignore"):
-            w = np.where(d < mx, ((mx - d) / mx) ** power_factor, 0.0)
-        return w
-    w = np.zeros_like(d)
-    w[np.arange(len(d)), np.argmin(d, axis=1)] = 1.0
-    return w
+        keys = d < mx
+        with np.errstate(invalid="ignore", under="ignore"):
+            w = np.where(keys, ((mx - d) / mx) ** power_factor, 0.0)
+    else:
+        w = np.zeros_like(d)
+        w[np.arange(len(d)), np.argmin(d, axis=1)] = 1.0
+        keys = w > 0
+    return (w, keys) if return_keys else w
 
 
 # --------------------------------------------------------------------------- #
@@ -162,11 +167,13 @@ def spatial_entropy_frame(dirs: np.ndarray, tiles: np.ndarray, fov_angle: float 
     Vectors in column order.  Returns (entropy, hist[n], nearest[U])."""
     if len(dirs) == 0:
         raise ValueError("Empty vector dictionary")
-    rows = tile_weight_rows(dirs, tiles, fov_angle, power_factor, use_weight_distribution)
+    rows, keys = tile_weight_rows(dirs, tiles, fov_angle, power_factor, use_weight_distribution, return_keys=True)
     hist = np.zeros(len(tiles))
     for r in rows:                      # user order, as the reference accumulates
         hist += r
-    touched = (rows > 0).any(axis=0) if use_weight_distribution else hist > 0
+    # the tiles in the reference's weight_per_tile dict: in some user's FoV, whatever the weight — a tile whose
+    # summed weight is 0.0 (or underflows against the total) makes the frame NaN (0 * log2 0, :195-198)
+    touched = keys.any(axis=0)
     near = nearest_tile(dirs, tiles)
     return spatial_entropy_from_hist(hist, touched, len(tiles), use_weight_distribution), hist, near
 
@@ -278,7 +285,7 @@ def spatial_series(mu: np.ndarray, mv: np.ndarray, W: int, H: int, tile_counts: 
     remap = np.full(D, -1, dtype=np.int64)
     remap[used] = np.arange(len(used))
     for k, L in enumerate(lattices):
-        rows = tile_weight_rows(flat[used], L, fov_angle, power_factor, use_weight_distribution)
+        rows, keys = tile_weight_rows(flat[used], L, fov_angle, power_factor, use_weight_distribution, return_keys=True)
         for t in range(T):
             ids = remap[did[t][present[t]]]
             if len(ids) == 0:
@@ -287,10 +294,12 @@ def spatial_series(mu: np.ndarray, mv: np.ndarray, W: int, H: int, tile_counts: 
             hist = np.zeros(len(L))
             for row in r:
                 hist += row
-            touched = (r > 0).any(axis=0)
+            touched = keys[ids].any(axis=0)
             ent[t] += spatial_entropy_from_hist(hist, touched, len(L), use_weight_distribution)
             if want_weights and k == 0:
-                weights[t] = hist
+                # dense convention of the C-ABI (include/vet.h): a tile that is a key of the reference's dict with
+                # the value 0.0 carries -0.0, a tile that is no key +0.0
+                weights[t] = np.where(touched & (hist == 0), -0.0, hist)
     return ent / len(lattices), assign, weights
 
 

@@ -72,3 +72,18 @@ def test_c_vs_numpy_oracle_with_absent_users():
     b = vo.transition_series(mu, mv, 100, 200, [50], closed_form=False)
     assert np.array_equal(a[1], b[1])
     np.testing.assert_allclose(a[0], b[0], rtol=RTOL, equal_nan=True)
+
+
+@pytest.mark.parametrize("tc,fov,power", [(50, 120, 150), (50, 60, 100), (500, 120, 80), (500, 120, 200), (500, 60, 150)])
+def test_c_underflowed_weights_give_nan(golden_dir, tc, fov, power):
+    """G12: in-FoV tiles whose weight underflows to 0.0 make the frame NaN (entropy_utils.py:131-135, 195-198)."""
+    g = np.load(golden_dir / "g12_underflow.npz")
+    tag = f"tc{tc}_fov{fov}_p{power}"
+    px, py = g["px"], g["py"]
+    mu = np.where(px >= 0, np.where(px == 100, 1.0, (px + 0.5) / 100.0), np.nan)
+    mv = np.where(px >= 0, np.where(py == 200, 1.0, (py + 0.5) / 200.0), np.nan)
+    ent, _, w = c_port.spatial_series(mu, mv, 100, 200, [tc], fov_angle=float(fov), power_factor=float(power), want_weights=True)
+    ref = g[f"{tag}__entropy"]
+    assert np.array_equal(np.isnan(ent), np.isnan(ref))
+    np.testing.assert_allclose(ent, ref, rtol=RTOL, atol=1e-15, equal_nan=True)
+    assert np.array_equal((w != 0) | np.signbit(w), g[f"{tag}__keys"])

@@ -195,3 +195,37 @@ def test_g10_naive_analyzer(golden_dir, th, tw, flag):
         assert sorted(keys) == [str(k) for k in g[f"{tag}__f{fi}_wkeys"]]
         assert np.array_equal(counts[np.argsort(keys)].astype(float), g[f"{tag}__f{fi}_wvals"])
         np.testing.assert_allclose(ent[fi], g[f"{tag}__f{fi}_entropy"], rtol=RTOL)
+
+
+G12_CONFIGS = [(tc, fov, power) for tc in (50, 500) for fov in (120, 60) for power in (50, 80, 100, 150, 200)]
+
+
+def g12_samples(g):
+    """G12's pixel coordinates as normalised samples (NaN = absent)."""
+    px, py = g["px"], g["py"]
+    present = px >= 0
+    mu = np.where(present, np.where(px == 100, 1.0, (px + 0.5) / 100.0), np.nan)
+    mv = np.where(present, np.where(py == 200, 1.0, (py + 0.5) / 200.0), np.nan)
+    return mu, mv
+
+
+@pytest.mark.parametrize("tc,fov,power", G12_CONFIGS)
+def test_g12_underflowed_weights_give_nan(golden_dir, tc, fov, power):
+    """FoV weights that underflow to 0.0 stay keys of the reference's dict and make the frame NaN
+    (entropy_utils.py:131-135, 195-198): NaN pattern, finite values and the 0.0-valued keys."""
+    g = load(golden_dir, "g12_underflow.npz")
+    tag = f"tc{tc}_fov{fov}_p{power}"
+    mu, mv = g12_samples(g)
+    ent, _, w = vo.spatial_series(mu, mv, 100, 200, [tc], fov_angle=float(fov), power_factor=float(power), want_weights=True)
+    ref = g[f"{tag}__entropy"]
+    assert np.array_equal(np.isnan(ent), np.isnan(ref))
+    np.testing.assert_allclose(ent, ref, rtol=RTOL, atol=1e-15, equal_nan=True)
+    keys = (w != 0) | np.signbit(w)
+    assert np.array_equal(keys, g[f"{tag}__keys"])
+    np.testing.assert_allclose(np.abs(w), g[f"{tag}__hist"], rtol=1e-9, atol=0)
+    grid = vo.direction_grid(100, 200)
+    L = vo.fibonacci_lattice(tc)
+    for f in (0, 7, 15, 20, 33):                    # the operator-level restatement too
+        ok = g["px"][f] >= 0
+        e, _, _ = vo.spatial_entropy_frame(grid[g["py"][f][ok], g["px"][f][ok]], L, float(fov), float(power))
+        np.testing.assert_allclose(e, ref[f], rtol=RTOL, atol=1e-15, equal_nan=True)
