@@ -133,6 +133,12 @@ int64_t vet_plan_n_dirs(const vet_plan *plan);
  * (k_row_stats; the contract is 1e-6); plans outside that — FoV cones narrower than the lattice
  * spacing, large power factors — run `ftable` (calls large enough for a table) or `precise`; those two
  * sum in FP64 and are reproducible to ~1e-15, not bit for bit (`ftable`: LDS atomics in arrival order).
+ * The reference's NaN frames: every tile with distance < fov/2 is a key of the reference's per-frame dict,
+ * also when ((max - d) / max) ** power_factor underflows to exactly 0.0 (entropy_utils.py:131-135), and a key
+ * whose summed weight is 0.0 (or underflows against the frame total) makes the entropy NaN = 0 * log2 0
+ * (:195-198).  Plans with such weights (below 2^-1048; power_factor >~ 80 on the default grids) never use an
+ * integer formulation; `precise` keeps the exact key set, and `ftable` keeps every in-FoV tile without an FP32
+ * value as a marker entry and hands the frames those markers decide to `precise` inside the same call.
  * Which formulation a call uses is a pure function of the plan and the call's shape, never of the
  * plan's history: policy 0 = table iff the call (or batch) holds >= 8 samples per direction of the
  * plan's direction table, +1 = table whenever it is inside the contract and fits, -1 = never table.
@@ -153,6 +159,8 @@ int vet_plan_read_nearest(vet_plan *plan, int lattice, int32_t *h_nearest /* [n_
  *   d_entropy [T]      mean over the plan's lattices of the normalised spatial entropy
  *   d_assign  [T*U]    nearest tile of lattice 0 per sample, -1 absent      (nullable)
  *   d_weights [T*n_0]  per-frame tile weight sums of lattice 0              (nullable)
+ *                      -0.0 = the tile is a key of the reference's dict with the value 0.0 (in some
+ *                      user's FoV, weight underflowed), +0.0 = no key        (`precise` rows only)
  *   d_present [T]      users present per frame                              (nullable)
  *   d_status  [2]      {#samples outside [0,1], #frames without a user}; the call ADDS to
  *                      it, the caller zeroes it                             (nullable)   */

@@ -208,3 +208,37 @@ def test_bench_rccl_pipelined_gather(workload):
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["value"] > 0
+
+
+def _engine_then_torch_worker(q):
+    _paths()
+    from viewport_entropy_toolkit import _native, _synthetic
+    eng, plan = _make_plans()                      # the engine's library (and a HIP runtime) first ...
+    mu, mv = _synthetic.random_walk_video(32, 64, base_seed=5)
+    ent = plan.spatial(mu=mu, mv=mv, want_assign=False)["entropy"]
+    import torch                                   # ... torch.cuda afterwards, in the same process
+    torch.cuda.set_device(0)
+    t = torch.arange(16, device="cuda", dtype=torch.float64)
+    ok_torch = float((t * 2).sum().item()) == 240.0
+    ent2 = plan.spatial(mu=mu, mv=mv, want_assign=False)["entropy"]
+    import re
+    runtimes = sorted(set(re.findall(r"\S*libamdhip64\S*", open("/proc/self/maps").read())))
+    q.put((ok_torch, bool(np.array_equal(ent, ent2)), runtimes, _native.HIP_RUNTIME_PRELOADED))
+    plan.close()
+
+
+def test_engine_first_then_torch_cuda():
+    """One HIP runtime per process whatever the import order: _native.load_library() preloads the runtime the
+    installed torch ships, so creating the engine first and touching torch.cuda afterwards works
+    (round 2: 'No HIP GPUs are available' in torch._C._cuda_init)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_engine_then_torch_worker, args=(q,))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    ok_torch, same, runtimes, preloaded = q.get(timeout=10)
+    assert ok_torch and same
+    assert len(runtimes) == 1, runtimes
+    assert preloaded and runtimes[0] == preloaded

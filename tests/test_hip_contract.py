@@ -39,6 +39,8 @@ def all_directions():
 # reference differ by as much: tests/golden was pinned at <= 1e-15).  It is 9 orders below an entropy of 1e-6.
 ATOL = 1e-15
 EXTREME = [([50], 30.0, 2.0), ([50], 120.0, 20.0), ([500], 5.0, 3.0), ([500], 10.0, 2.0), ([50], 120.0, 50.0)]
+# power factors whose weights underflow: the reference's NaN frames (entropy_utils.py:131-135, 195-198; golden G12)
+UNDERFLOW = [([500], 120.0, 100.0), ([50], 120.0, 200.0), ([500], 60.0, 150.0)]
 _ORACLE = {}
 
 
@@ -61,7 +63,7 @@ def oracle_for(tcs, fov, power, name, mu, mv):
     return _ORACLE[key]
 
 
-@pytest.mark.parametrize("tcs,fov,power", EXTREME + [([500], 120.0, 2.0), ([20, 50], 120.0, 2.0)])
+@pytest.mark.parametrize("tcs,fov,power", EXTREME + UNDERFLOW + [([500], 120.0, 2.0), ([20, 50], 120.0, 2.0)])
 @pytest.mark.parametrize("policy", [1, -1, 0])
 def test_single_and_two_user_frames_over_all_directions(native, engine, tcs, fov, power, policy):
     cases = contract_cases()

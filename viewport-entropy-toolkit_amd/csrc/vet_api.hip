@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <array>
 #include <string>
 #include <unordered_map>
@@ -101,6 +102,9 @@ struct Lattice {
     bool stats_done = false;
     double crit_tab = 0.0;         // table formulation (step 2^(e_row - 33) per entry)
     double crit_base = 0.0;        // times the step of the sweep formulation
+    long ultra = 0;                // in-FoV (direction, tile) pairs whose weight is below 2^-1048 (k_row_stats): the
+                                   // reference's NaN frames; such plans never use an integer formulation
+    int markers = 0;               // marker entries of the FP table (k_wtab): frames they decide go to the precise sweep
     int last_form = -1;            // formulation of the last weighted call (parity / bench introspection)
     int stride = 0;                // 0 = not built, -1 = not usable (too large)
     int gs_log2 = 4;               // lanes per gather group (log2); fixed when the table is built
@@ -124,6 +128,8 @@ struct vet_plan {
     uint32_t* d_alias = nullptr;   // [n_dirs] direction id -> table row | mirrored << 31 (ensure_alias)
     bool mirror = false;           // rows are shared between mirror-image directions
     uint2* d_dirrec = nullptr;     // [n_dirs] alias | nearest tile | lattice-0 row meta (k_dirrec), dedup-capable plans
+    bool stats_all = false;        // k_row_stats has run for every weighted lattice
+    bool ultra = false;            // some lattice has ultra-tiny in-FoV weights: FP64 formulations only (plan-wide)
 };
 
 namespace {
@@ -206,7 +212,7 @@ struct Geometry {
 };
 
 // launch geometry of the spatial kernels for a lattice of n tiles and U users
-int spatial_geometry(const vet_ctx* c, int n, int U, bool weighted, Geometry* g) {
+int spatial_geometry(const vet_ctx* c, int n, int U, bool weighted, Geometry* g, bool one_frame = false) {
     if (!weighted) {
         // k_spatial_u: one wave per frame in the entropy phase; keep >= 2048 samples per workgroup
         g->R = 1; g->G = 1; g->UC = 0;
@@ -224,6 +230,7 @@ int spatial_geometry(const vet_ctx* c, int n, int U, bool weighted, Geometry* g)
     g->G = (n + vet::WAVE * g->R - 1) / (vet::WAVE * g->R);
     if (g->G >= 4) { g->NW = g->G > 16 ? 16 : g->G; g->FPW = 1; }
     else { g->NW = 4; g->FPW = 4 / g->G; }
+    if (one_frame) g->FPW = 1;
     g->UC = U < 1024 ? U : 1024;
     auto lds_of = [&](int fpw, int uc) {
         size_t b = (size_t)fpw * n * 8;
@@ -347,13 +354,13 @@ int ensure_stats(vet_plan* pl, int k, hipStream_t s) {
     if (L.stats_done) return VET_OK;
     vet_ctx* c = pl->ctx;
     unsigned long long* d_crit = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_crit, 16));
+    HIP_TRY(hipMalloc((void**)&d_crit, 24));
     if ((!L.d_row_s && hipMalloc((void**)&L.d_row_s, (size_t)pl->n_dirs + 1) != hipSuccess) ||
         (!L.d_row_e && hipMalloc((void**)&L.d_row_e, ((size_t)pl->n_dirs + 1) * 2) != hipSuccess)) {
         (void)hipFree(d_crit);
         return fail(VET_ERR_DEVICE, "hipMalloc of the row shift table failed");
     }
-    hipError_t e = hipMemsetAsync(d_crit, 0, 16, s);
+    hipError_t e = hipMemsetAsync(d_crit, 0, 24, s);
     vet::StatsParams p;
     p.dir_unit = pl->d_dir_unit; p.D = (long)pl->n_dirs;
     p.tiles = L.d_tiles; p.n = L.n;
@@ -365,14 +372,31 @@ int ensure_stats(vet_plan* pl, int k, hipStream_t s) {
         ProfScope ps(c, s, KID_WTAB);
         hipLaunchKernelGGL(vet::k_row_stats, dim3(blocks), dim3(256), 0, s, p);
     }
-    unsigned long long bits[2] = {0, 0};
-    if (e == hipSuccess) e = hipMemcpyAsync(bits, d_crit, 16, hipMemcpyDeviceToHost, s);
+    unsigned long long bits[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(bits, d_crit, 24, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(d_crit);
     if (e != hipSuccess) return fail(VET_ERR_DEVICE, "k_row_stats failed: %s", hipGetErrorString(e));
     memcpy(&L.crit_tab, &bits[0], 8);
     memcpy(&L.crit_base, &bits[1], 8);
+    L.ultra = (long)bits[2];
     L.stats_done = true;
+    return VET_OK;
+}
+
+// statistics of every weighted lattice; whether the plan has ultra-tiny weights is a plan-wide fact (the lattices
+// of a fused table launch must be of one kind)
+int ensure_all_stats(vet_plan* pl, hipStream_t s) {
+    if (pl->stats_all) return VET_OK;
+    bool ultra = false;
+    for (int k = 0; k < (int)pl->lat.size(); ++k) {
+        if (!pl->weighted || pl->lat[k].binned) continue;
+        int rc = ensure_stats(pl, k, s);
+        if (rc) return rc;
+        ultra = ultra || pl->lat[k].ultra > 0;
+    }
+    pl->ultra = ultra;
+    pl->stats_all = true;
     return VET_OK;
 }
 
@@ -383,22 +407,23 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     Lattice& L = pl->lat[k];
     if (L.stride != 0) return VET_OK;
     vet_ctx* c = pl->ctx;
-    int rc = ensure_stats(pl, k, s);
+    int rc = ensure_all_stats(pl, s);
     if (rc) return rc;
     rc = ensure_alias(pl);
     if (rc) return rc;
-    int* d_max = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_max, sizeof(int)));
-    hipError_t e = hipMemsetAsync(d_max, 0, sizeof(int), s);
+    int* d_max = nullptr;                      // [0] longest row (count pass), [1] marker entries (fill pass)
+    HIP_TRY(hipMalloc((void**)&d_max, 2 * sizeof(int)));
+    struct FreeMax { int* p; ~FreeMax() { (void)hipFree(p); } } free_max{d_max};
+    hipError_t e = hipMemsetAsync(d_max, 0, 2 * sizeof(int), s);
     vet::WtabParams p;
     p.dir_unit = pl->d_dir_unit; p.D = (long)pl->n_dirs;
     p.tiles = L.d_tiles; p.n = L.n;
     p.cos_cull = pl->cos_cull;
     p.wc.max_ang = pl->max_ang; p.wc.inv_max = 1.0 / pl->max_ang; p.wc.power = pl->power; p.wc.shift = 0;
     // integer mantissas where their error bound is inside the contract, FP32 weights otherwise
-    L.fp_table = !(L.crit_tab <= kContractMargin);
+    L.fp_table = pl->ultra || !(L.crit_tab <= kContractMargin);
     p.stride = 0; p.w = nullptr; p.idx = nullptr; p.meta = nullptr; p.row_s = L.d_row_s; p.row_e = L.d_row_e; p.fp = L.fp_table ? 1 : 0;
-    p.maxcount = d_max; p.gs_log2 = -1;
+    p.maxcount = d_max; p.markers = nullptr; p.gs_log2 = -1;
     const int blocks = grid_for((long)pl->n_dirs * vet::WAVE, 256, c->n_cu * 2);
     {
         ProfScope ps(c, s, KID_WTAB);
@@ -407,7 +432,6 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     int longest = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&longest, d_max, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d_max);
     if (e != hipSuccess) return fail(VET_ERR_DEVICE, "k_wtab<count> failed: %s", hipGetErrorString(e));
     int align = 64;      // rows start on 128-byte lines (u16 tile rows) / 256 bytes (u32 weight rows)
     align = (env_int("VET_STRIDE_ALIGN", 64, 1024, align) + 63) / 64 * 64;   // whole 64-entry blocks: the walk reads whole blocks
@@ -444,19 +468,25 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     L.interleaved = L.gs_log2 == 4 && stride % 64 == 0 && 4 * longest >= 3 * 64;
     L.interleaved = L.interleaved && env_int("VET_TAB_INTERLEAVE", 0, 1, 1) != 0;
     p.stride = stride; p.w = L.d_tab_w; p.idx = L.d_tab_i; p.meta = L.d_tab_meta; p.maxcount = nullptr;
+    p.markers = L.fp_table ? d_max + 1 : nullptr;
     p.gs_log2 = L.interleaved ? L.gs_log2 : -1;
     {
         ProfScope ps(c, s, KID_WTAB);
         hipLaunchKernelGGL(vet::k_wtab<true>, dim3(blocks), dim3(256), 0, s, p);
     }
     HIP_TRY(hipGetLastError());
-    L.stride = stride;
     if (k == 0 && (uint64_t)pl->n_dirs <= vet::DEDUP_MAX_DIRS) {
         if (!pl->d_dirrec) HIP_TRY(hipMalloc((void**)&pl->d_dirrec, (size_t)pl->n_dirs * sizeof(uint2)));
         hipLaunchKernelGGL(vet::k_dirrec, dim3(grid_for(pl->n_dirs, 256, c->n_cu)), dim3(256), 0, s, pl->d_alias,
                            L.d_nearest, L.d_tab_meta, (long)pl->n_dirs, pl->d_dirrec);
         HIP_TRY(hipGetLastError());
     }
+    // the table is complete before this returns: a later call may run on another stream (first use only)
+    int markers = 0;
+    HIP_TRY(hipMemcpyAsync(&markers, d_max + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    L.markers = markers;
+    L.stride = stride;
     return VET_OK;
 }
 
@@ -505,6 +535,7 @@ int sweep_shift(int U) {
 
 // integer sweep if its error bound is inside the contract, FP64 sweep otherwise
 int sweep_formulation(const vet_plan* pl, const Lattice& L, int U) {
+    if (pl->ultra) return F_PRECISE;          // the reference's NaN frames need the exact key set
     // the sweep truncates at 2^(shift-52); its fast arc cosine (fov <= 120, power 1 or 2) is good to 4e-14
     double step = std::ldexp(1.0, sweep_shift(U) - 52);
     if (weight_mode(pl) != 0 && step < 4e-14) step = 4e-14;
@@ -514,7 +545,7 @@ int sweep_formulation(const vet_plan* pl, const Lattice& L, int U) {
 // formulation of lattice k for a call; builds the statistics (and the table) on first use
 int choose_formulation(vet_plan* pl, int k, bool want_table, int U, hipStream_t s, int* out) {
     Lattice& L = pl->lat[k];
-    int rc = ensure_stats(pl, k, s);
+    int rc = ensure_all_stats(pl, s);
     if (rc) return rc;
     if (want_table) {
         rc = ensure_wtab(pl, k, s);
@@ -530,10 +561,11 @@ template <bool FROM_IDS>
 int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& src, int U, int T,
                const vet::VideoDesc* d_videos, int n_videos, int blocks_batch, size_t lds_batch, int batch_max_users,
                double* d_entropy, int32_t* d_assign, double* d_weights, int32_t* d_present, int32_t* d_status,
-               hipStream_t s, bool* launched) {
+               hipStream_t s, bool* launched, uint32_t* d_resolve = nullptr) {
     vet_ctx* c = pl->ctx;
     *launched = false;
     vet::LutParams q;
+    q.resolve = d_resolve;
     q.videos = d_videos; q.n_videos = n_videos;
     q.src = src; q.U = U; q.T = T;
     q.nearest = pl->lat[lat_idx[0]].d_nearest;
@@ -567,7 +599,7 @@ int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& sr
         int fpw = lut_frames_per_wg(U, T, c->n_cu, q.n_sum);
         fpw = env_int("VET_LUT_FPW", 1, 16, fpw);
         for (;; fpw /= 2) {
-            lds = vet::lut_lds_bytes(U, q.UC, fpw, q.n_sum, dedup);
+            lds = vet::lut_lds_bytes(U, q.UC, fpw, q.n_sum, dedup, d_resolve != nullptr);
             if (lds <= c->lds_max || fpw == 1) break;
         }
         if (lds > c->lds_max) return VET_OK;      // not launched: caller falls back to the sweep
@@ -601,6 +633,60 @@ size_t batch_video_geometry(const vet_ctx* c, int U, long total_frames, int n_su
     return lds <= c->lds_max ? lds : 0;
 }
 
+// markers in the FP tables of lattices lat_idx[0..K)?  Then the launch needs a resolve list (pool slot 9): [0] = count
+int resolve_list_for(vet_plan* pl, const int* lat_idx, int K, int T, hipStream_t s, uint32_t** out) {
+    *out = nullptr;
+    bool any = false;
+    for (int k = 0; k < K; ++k) any = any || (pl->lat[lat_idx[k]].fp_table && pl->lat[lat_idx[k]].markers > 0);
+    if (!any) return VET_OK;
+    void* buf = nullptr;
+    int rc = pooled(pl->ctx, 9, ((size_t)T + 1) * sizeof(uint32_t), &buf);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(buf, 0, sizeof(uint32_t), s));
+    *out = (uint32_t*)buf;
+    return VET_OK;
+}
+
+// The frames a table launch could not decide (a key of the reference's dict whose table weight sum is 0.0) run
+// through the precise sweep — exact weights, exact key set — which overwrites their entropy (and weights row):
+// NaN where the reference's 0 * log2 0 gives NaN (entropy_utils.py:195-198).  out = the launch's entropy output
+// ([T]: one lattice's row, or the mean over the K fused lattices; ws then holds the per-lattice values).
+template <bool FROM_IDS>
+int resolve_frames(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& src, int U, int T, double* out,
+                   double* d_weights, const uint32_t* d_list, double* ws, hipStream_t s) {
+    vet_ctx* c = pl->ctx;
+    for (int k = 0; k < K; ++k) {
+        const Lattice& L = pl->lat[lat_idx[k]];
+        Geometry g;
+        int rc = spatial_geometry(c, L.n, U, true, &g, true);
+        if (rc) return rc;
+        vet::SpatialParams p;
+        p.src = src; p.U = U; p.T = T;
+        p.dir_unit = pl->d_dir_unit; p.nearest = L.d_nearest; p.tiles = L.d_tiles; p.n = L.n;
+        p.cos_cull = pl->cos_cull;
+        p.wc.max_ang = pl->max_ang; p.wc.inv_max = 1.0 / pl->max_ang; p.wc.power = pl->power; p.wc.shift = 0;
+        p.hmax = L.hmax;
+        p.ent_k = K == 1 ? out : ws + (size_t)k * T;
+        p.assign = nullptr; p.present = nullptr; p.status = nullptr;       // written by the table launch
+        p.weights = (k == 0 && lat_idx[0] == 0) ? d_weights : nullptr;
+        p.FPW = 1; p.G = g.G; p.UC = g.UC;
+        p.log2_tab = c->d_log2; p.full_norm = 0; p.norm_n = L.norm_n;
+        p.frame_list = d_list;
+        long grid = (long)c->n_cu * 4;
+        if (grid > T) grid = T;
+        void* args[] = {(void*)&p};
+        ProfScope ps(c, s, KID_SPATIAL);
+        HIP_TRY(hipLaunchKernel(spatial_w_kernel<FROM_IDS>(0, g.R, true), dim3((unsigned)grid), dim3(g.NW * vet::WAVE), args, g.lds, s));
+    }
+    if (K > 1) {
+        ProfScope ps(c, s, KID_FINALIZE);
+        hipLaunchKernelGGL(vet::k_finalize_list, dim3(grid_for(T, 256, c->n_cu)), dim3(256), 0, s, (const double*)ws, K, (long)T,
+                           d_list, out);
+        HIP_TRY(hipGetLastError());
+    }
+    return VET_OK;
+}
+
 template <bool FROM_IDS>
 int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double* d_entropy, int32_t* d_assign,
                    double* d_weights, int32_t* d_present, int32_t* d_status, hipStream_t s) {
@@ -625,9 +711,18 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         int idx[vet::MAX_LATTICES];
         for (int k = 0; k < K; ++k) idx[k] = k;
         bool launched = false;
-        int rc = launch_lut<FROM_IDS>(pl, idx, K, src, U, T, nullptr, 0, 0, 0, 0, d_entropy, d_assign, d_weights, d_present,
-                                      d_status, s, &launched);
+        uint32_t* d_list = nullptr;
+        int rc = resolve_list_for(pl, idx, K, T, s, &d_list);
+        if (rc) return rc;
+        if (d_list && K > 1) {
+            rc = ensure_ws(c, (size_t)K * T * sizeof(double));
+            if (rc) return rc;
+        }
+        rc = launch_lut<FROM_IDS>(pl, idx, K, src, U, T, nullptr, 0, 0, 0, 0, d_entropy, d_assign, d_weights, d_present,
+                                  d_status, s, &launched, d_list);
         if (launched) for (int k = 0; k < K; ++k) pl->lat[k].last_form = form[k];
+        if (!rc && launched && d_list)
+            rc = resolve_frames<FROM_IDS>(pl, idx, K, src, U, T, d_entropy, d_weights, d_list, (double*)c->ws, s);
         if (rc || launched) return rc;
         for (int k = 0; k < K; ++k) form[k] = sweep_formulation(pl, pl->lat[k], U);   // histograms do not fit the LDS
     }
@@ -640,9 +735,14 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         const Lattice& L = pl->lat[k];
         if (form[k] == F_TABLE || form[k] == F_FTABLE) {
             bool launched = false;
-            int rc = launch_lut<FROM_IDS>(pl, &k, 1, src, U, T, nullptr, 0, 0, 0, 0, ent_k + (size_t)k * T,
-                                          k == 0 ? d_assign : nullptr, k == 0 ? d_weights : nullptr,
-                                          k == 0 ? d_present : nullptr, k == 0 ? d_status : nullptr, s, &launched);
+            uint32_t* d_list = nullptr;
+            int rc = resolve_list_for(pl, &k, 1, T, s, &d_list);
+            if (rc) return rc;
+            rc = launch_lut<FROM_IDS>(pl, &k, 1, src, U, T, nullptr, 0, 0, 0, 0, ent_k + (size_t)k * T,
+                                      k == 0 ? d_assign : nullptr, k == 0 ? d_weights : nullptr,
+                                      k == 0 ? d_present : nullptr, k == 0 ? d_status : nullptr, s, &launched, d_list);
+            if (!rc && launched && d_list)
+                rc = resolve_frames<FROM_IDS>(pl, &k, 1, src, U, T, ent_k + (size_t)k * T, d_weights, d_list, nullptr, s);
             if (rc) return rc;
             if (launched) { pl->lat[k].last_form = form[k]; continue; }
             form[k] = sweep_formulation(pl, L, U);
@@ -676,6 +776,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         p.log2_tab = c->d_log2;
         p.full_norm = (L.binned && pl->weighted) ? 1 : 0;
         p.norm_n = L.norm_n;
+        p.frame_list = nullptr;
         if (!hist_weighted && !FROM_IDS && U <= 4096 && !getenv("VET_U_NO_LDS")) {
             // persistent variant with the nearest LUT in LDS: a round is 4096 users = FB frames
             // (2048 pairs with 16-byte loads when U is even, 4096 single users otherwise)
@@ -1154,10 +1255,12 @@ int vet_plan_error_bounds(vet_plan* pl, int k, double* table_bound, double* swee
     if (k < 0 || k >= (int)pl->lat.size()) return fail(VET_ERR_INVALID, "lattice index %d out of range", k);
     if (pl->lat[k].binned) return fail(VET_ERR_INVALID, "lattice %d is binned (integer counts, exact)", k);
     HIP_TRY(hipSetDevice(pl->ctx->device));
-    int rc = ensure_stats(pl, k, pl->ctx->stream);
+    int rc = ensure_all_stats(pl, pl->ctx->stream);
     if (rc) return rc;
-    if (table_bound) *table_bound = pl->lat[k].crit_tab;
-    if (sweep_bound) *sweep_bound = pl->lat[k].crit_base * std::ldexp(1.0, -52);
+    // plans with weights that underflow (the reference's NaN frames) never use an integer formulation
+    const double inf = std::numeric_limits<double>::infinity();
+    if (table_bound) *table_bound = pl->ultra ? inf : pl->lat[k].crit_tab;
+    if (sweep_bound) *sweep_bound = pl->ultra ? inf : pl->lat[k].crit_base * std::ldexp(1.0, -52);
     return VET_OK;
 }
 
@@ -1252,6 +1355,7 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
         if (rc) return rc;
         if (k == 0) form0 = form;
         table = (form == F_TABLE || form == F_FTABLE) && form == form0;      // one launch: tables of one kind
+        table = table && pl->lat[k].markers == 0;                            // marker tables need the per-video resolver
     }
     int n_sum = 0;
     for (int k = 0; k < K; ++k) n_sum += pl->lat[k].n;
@@ -1315,7 +1419,7 @@ static int pooled(vet_ctx* c, int slot, size_t bytes, void** out) {
 #define POOL(slot, bytes, var) do { int rc_ = pooled(c, slot, bytes, &var); if (rc_) return rc_; } while (0)
 
 struct vet_result {
-    vet_ctx* ctx = nullptr;
+    int device = 0;                      // the result may outlive its context: only the device id is kept
     void* d[2] = {nullptr, nullptr};     // 0: assign / pairs, 1: weights / srccount
     size_t row_bytes[2] = {0, 0};
     int64_t rows = 0;
@@ -1353,7 +1457,7 @@ static int run_host(vet_plan* pl, bool transition, const double* h_mu, const dou
         // the optional outputs stay in device memory of their own, owned by the result handle
         *keep = nullptr;
         res = new vet_result();
-        res->ctx = c;
+        res->device = c->device;
         res->rows = R > 0 ? R : 0;
         res->row_bytes[0] = transition ? (size_t)U * 2 * 4 : (size_t)U * 4;
         res->row_bytes[1] = transition ? (size_t)n0 * 4 : (size_t)n0 * 8;
@@ -1419,7 +1523,7 @@ int vet_result_fetch(vet_result* r, int which, int64_t row0, int64_t n_rows, voi
         return fail(VET_ERR_INVALID, "rows [%lld, %lld) outside the result's %lld rows", (long long)row0,
                     (long long)(row0 + n_rows), (long long)r->rows);
     if (n_rows == 0) return VET_OK;
-    HIP_TRY(hipSetDevice(r->ctx->device));
+    HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipMemcpy(h_dst, (const char*)r->d[which] + (size_t)row0 * r->row_bytes[which], (size_t)n_rows * r->row_bytes[which],
                       hipMemcpyDeviceToHost));
     return VET_OK;
@@ -1427,7 +1531,7 @@ int vet_result_fetch(vet_result* r, int which, int64_t row0, int64_t n_rows, voi
 
 int vet_result_free(vet_result* r) {
     if (!r) return VET_OK;
-    if (r->ctx) (void)hipSetDevice(r->ctx->device);
+    (void)hipSetDevice(r->device);
     for (void* q : r->d) if (q) (void)hipFree(q);
     delete r;
     return VET_OK;

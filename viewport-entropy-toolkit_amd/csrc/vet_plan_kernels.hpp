@@ -76,4 +76,16 @@ __global__ void k_finalize(const double* __restrict__ ent_k, int K, long rows, d
     }
 }
 
+// the same for the frames of a resolve list only ([0] = count, then the frames)
+__global__ void k_finalize_list(const double* __restrict__ ent_k, int K, long rows, const uint32_t* __restrict__ list,
+                                double* __restrict__ out) {
+    const long n = (long)list[0];
+    for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < n; j += (long)gridDim.x * blockDim.x) {
+        const long i = (long)list[1 + j];
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += ent_k[(long)k * rows + i];
+        out[i] = s / (double)K;
+    }
+}
+
 }  // namespace vet

@@ -19,11 +19,14 @@ constexpr uint32_t ROW_MASK = (1u << ROW_BITS) - 1;
 
 // FPT: FP table — entries are FP32 weights (relative precision 2^-24 each: |dH|/H <= 1.2e-7 for every frame, whatever the
 // weights' dynamic range), scaled by 2^E of their row; the histogram is FP64 (ds_add_f64) in true units.
+// marked / bit0: FP tables with marker entries (vet_weight_table.hpp) — bitmap of the frame's tiles (bit0 = the lattice's
+// first bit) that were hit by a marker; null when the launch's tables hold none.
 template <int UN, bool INTERLEAVED, bool DEDUP, bool FPT>
 __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t* fmeta, int nu,
                                           unsigned long long* hrow, int n,
                                           const uint32_t* __restrict__ tab_w, const uint16_t* __restrict__ tab_i,
-                                          int stride, int gs_log2_rt, uint32_t zero_row) {
+                                          int stride, int gs_log2_rt, uint32_t zero_row,
+                                          uint32_t* marked = nullptr, int bit0 = 0) {
     // Every lane takes one 4-slot chunk per block: one 16-byte load of weights, one 8-byte load of
     // tiles (stride is a multiple of the block, so chunks are 16 / 8 byte aligned), then four
     // unconditional ds_add_u64 of entry * (multiplicity << row shift): padding slots and idle lanes
@@ -84,6 +87,16 @@ __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t*
 #pragma unroll
             for (int k = 0; k < UN; ++k) {
                 if (FPT) {
+                    if (marked) {
+                        const uint32_t wk[4] = {w[k].x, w[k].y, w[k].z, w[k].w};
+                        const int tk[4] = {(int)t[k].x, (int)t[k].y, (int)t[k].z, (int)t[k].w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (wk[c] == MARKER_BITS) {
+                                const int bit = bit0 + (sgn[k] < 0 ? n - 1 - tk[c] : tk[c]);
+                                atomicOr(&marked[bit >> 5], 1u << (bit & 31));
+                            }
+                    }
                     atomicAdd((double*)(hb[k] + (int)t[k].x * sgn[k]), (double)__uint_as_float(w[k].x) * scale[k]);
                     atomicAdd((double*)(hb[k] + (int)t[k].y * sgn[k]), (double)__uint_as_float(w[k].y) * scale[k]);
                     atomicAdd((double*)(hb[k] + (int)t[k].z * sgn[k]), (double)__uint_as_float(w[k].z) * scale[k]);
@@ -158,6 +171,8 @@ struct LutParams {
     int32_t* present;
     int32_t* status;
     int FPW, UC;
+    uint32_t* resolve;            // FP tables with marker entries: [0] = number of frames handed to the precise sweep
+                                  // (a marked tile whose histogram stayed 0.0), then the frames; null otherwise
 };
 
 // hash slots per frame: power of two >= 2 * UC, at least one wave's worth
@@ -167,10 +182,12 @@ __host__ __device__ __forceinline__ int lut_hash_slots(int UC) {
     return hs;
 }
 // LDS bytes of a workgroup; the kernel and the host must agree
-__host__ __device__ __forceinline__ size_t lut_lds_bytes(int U, int UC, int FPW, int n_sum, bool dedup) {
+__host__ __device__ __forceinline__ int lut_marked_words(int n_sum) { return (n_sum + 31) >> 5; }
+__host__ __device__ __forceinline__ size_t lut_lds_bytes(int U, int UC, int FPW, int n_sum, bool dedup, bool marked = false) {
     const size_t hist = (size_t)FPW * n_sum * 8, hash = dedup ? (size_t)FPW * lut_hash_slots(UC) * 4 : 0;
     const size_t a = (dedup && U <= UC) ? (hist > hash ? hist : hash) : hist + hash;
-    return ((a + 15) & ~(size_t)15) + (size_t)FPW * UC * 8 + (size_t)2 * FPW * 4 + 64;
+    return ((a + 15) & ~(size_t)15) + (size_t)FPW * UC * 8 + (size_t)2 * FPW * 4 + 64 +
+           (marked ? (size_t)FPW * lut_marked_words(n_sum) * 4 : 0);
 }
 
 // All K lattices of the plan in one launch: the samples are read once, every row is gathered into K
@@ -214,6 +231,8 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
     uint32_t* meta = rows + (size_t)FPW * UC;                                    // [FPW][UC]
     int* cnt_chunk = (int*)(meta + (size_t)FPW * UC);                            // [FPW]
     int* cnt_frame = cnt_chunk + FPW;                                            // [FPW]
+    const int MW = lut_marked_words(p.n_sum);
+    uint32_t* marked = (FPT && p.resolve) ? (uint32_t*)(cnt_frame + FPW) : nullptr;   // [FPW][MW]
     const int NW = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const long f0 = blk * FPW;
@@ -221,6 +240,8 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
     if (!overlay)
         for (int i = tid; i < FPW * p.n_sum; i += blockDim.x) hist[i] = 0ull;
     for (int i = tid; i < 2 * FPW; i += blockDim.x) cnt_chunk[i] = 0;
+    if (FPT && marked)
+        for (int i = tid; i < FPW * MW; i += blockDim.x) marked[i] = 0u;
     bool bad = false;
     const int hs_shift = 32 - (31 - __clz(HS | 1));
     for (int u0 = 0; u0 < U; u0 += UC) {
@@ -370,11 +391,11 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
                 if (IL && L.interleaved)
                     walk_rows<UN, true, DEDUP, FPT>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
                                                hist + (size_t)fl * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
-                                               (uint32_t)src.n_dirs * (uint32_t)L.stride);
+                                               (uint32_t)src.n_dirs * (uint32_t)L.stride, marked ? marked + (size_t)fl * MW : nullptr, hoff);
                 else
                     walk_rows<UN, false, DEDUP, FPT>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
                                                 hist + (size_t)fl * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
-                                                (uint32_t)src.n_dirs * (uint32_t)L.stride);
+                                                (uint32_t)src.n_dirs * (uint32_t)L.stride, marked ? marked + (size_t)fl * MW : nullptr, hoff);
             hoff += L.n;
         }
     }
@@ -384,6 +405,8 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
     for (int fl = wv; fl < nf; fl += NW) {
         const unsigned long long* hrow = hist + (size_t)fl * p.n_sum;
         double total_entropy = 0.0;
+        bool unresolved = false;           // a key of the reference's dict (marker hit) whose table weight sum is 0.0
+        int bit0 = 0;
         for (int k = 0; k < p.K; ++k) {
             const int n = p.lat[k].n;
             // total weight can exceed 64 bits of fixed point: summed in FP64, fixed lane order + butterfly
@@ -398,11 +421,18 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
                     h -= q * log2(q);
                 }
                 if (k == 0 && weights) __builtin_nontemporal_store(FPT ? v : v * inv_unit, weights + (f0 + fl) * (long)n + t);
+                if (FPT && marked && v == 0.0) {
+                    const int bit = bit0 + t;
+                    unresolved = unresolved || ((marked[(size_t)fl * MW + (bit >> 5)] >> (bit & 31)) & 1u) != 0u;
+                }
             }
             h = wave_sum(h);
             total_entropy += h / p.lat[k].hmax;
             hrow += n;
+            bit0 += n;
         }
+        if (FPT && marked && __ballot(unresolved) != 0ull && lane == 0)
+            p.resolve[1 + atomicAdd(&p.resolve[0], 1u)] = (uint32_t)(f0 + fl);
         if (lane == 0) {
             const int np = cnt_frame[fl];
             double e = total_entropy / (double)p.K;

@@ -44,14 +44,67 @@ struct SpatialParams {
     int norm_n;                   // tile count the user count is compared with (= n except binned lattices)
     int full_norm;                // unweighted kernels: always normalise by log2(n) (binned lattices
                                   // with use_weight_distribution, entropy_utils.py:442-447)
+    const uint32_t* frame_list;   // precise sweep as the table kernel's resolver: [0] = number of frames, then the
+                                  // frames (any order); null = all T frames, blockIdx.x * FPW onwards
 };
 
-// the reference's weight, evaluated as the reference does (entropy_utils.py:124-137): 0 when not d < max
-__device__ __forceinline__ double fov_weight_exact(double c, const WeightCfg& w) {
+// the reference's FoV test and weight, evaluated as the reference does (entropy_utils.py:124-137).  True when
+// distance < max: the tile is then a key of the reference's dict WHATEVER the weight — a power factor large
+// enough makes (..) ** power underflow to exactly 0.0, the key stays (and 0 * log2 0 makes the frame NaN, :195-198).
+__device__ __forceinline__ bool fov_weight_cone(double c, const WeightCfg& w, double& wt) {
     c = fmin(fmax(c, -1.0), 1.0);
     const double d = acos(c);
-    if (!(d < w.max_ang)) return 0.0;
-    return pow((w.max_ang - d) / w.max_ang, w.power);
+    wt = 0.0;
+    if (!(d < w.max_ang)) return false;
+    wt = pow((w.max_ang - d) / w.max_ang, w.power);
+    return true;
+}
+__device__ __forceinline__ double fov_weight_exact(double c, const WeightCfg& w) {
+    double wt;
+    (void)fov_weight_cone(c, w, wt);
+    return wt;
+}
+
+// "no key" marker of the FP64 histograms that keep the reference's key set: -0.0.  x + (+0.0) turns it into +0.0
+// (IEEE round to nearest), so a tile that only ever received weights of exactly 0.0 reads +0.0 = "key with the
+// value 0.0", and every positive weight adds as if the slot had held 0.
+constexpr unsigned long long NO_KEY_BITS = 0x8000000000000000ull;
+
+// Entropy of the workgroup's frames from FP64 histograms that keep the key set (precise sweep; entropy_utils.py:
+// 194-211, weighted mode).  Every key contributes -p log2 p, also p == 0 (-> NaN, as numpy's 0 * -inf).
+// Dense weights output: key with the value 0.0 -> -0.0, no key -> +0.0 (include/vet.h).
+__device__ __forceinline__ void keyed_frame_entropy(const double* hist, const int* cnt_frame, int nf, long f0, int n,
+                                                    double hmax, double* ent_k, double* weights, int32_t* present,
+                                                    int32_t* status, const uint32_t* frames) {
+    const int NW = blockDim.x >> 6, lane = lane_id(), wv = wave_id();
+    for (int fl = wv; fl < nf; fl += NW) {
+        const double* hrow = hist + (size_t)fl * n;
+        const long f = frames ? (long)frames[fl] : f0 + fl;
+        double totd = 0.0;
+        for (int t = lane; t < n; t += WAVE) totd += hrow[t];          // -0.0 adds nothing
+        totd = wave_sum(totd);
+        double h = 0.0;
+        for (int t = lane; t < n; t += WAVE) {
+            const double v = hrow[t];
+            const bool key = (unsigned long long)__double_as_longlong(v) != NO_KEY_BITS;
+            if (key) {
+                const double q = v / totd;
+                h -= q * log2(q);
+            }
+            if (weights) __builtin_nontemporal_store(key ? (v == 0.0 ? -0.0 : v) : 0.0, weights + f * (long)n + t);
+        }
+        h = wave_sum(h);
+        if (lane == 0) {
+            const int np = cnt_frame[fl];
+            double e = h / hmax;
+            if (np == 0) {
+                e = __builtin_nan("");
+                if (status) atomicAdd(&status[1], 1);
+            }
+            ent_k[f] = e;
+            if (present) present[f] = np;
+        }
+    }
 }
 
 // PRECISE: the histogram is FP64 (ds_add_f64) and the weights are the exact ocml values, for plans whose
@@ -73,14 +126,21 @@ __global__ void k_spatial_w(const SpatialParams p) {
     int* cnt_frame = cnt_chunk + p.FPW;                                          // [FPW]
 
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
-    const long f0 = (long)blockIdx.x * p.FPW;
-    const int nf = (int)min((long)p.FPW, (long)p.T - f0);
-
-    for (int i = tid; i < p.FPW * p.n; i += blockDim.x) hist[i] = (HT)0;
-    for (int i = tid; i < 2 * p.FPW; i += blockDim.x) cnt_chunk[i] = 0;
     bool bad = false;
     double* my_qc = qc + wv * QC;
     uint16_t* my_qt = qt + wv * QC;
+    // blocks of FPW frames: this workgroup's own (blockIdx.x), or — resolver mode — the listed frames one at a
+    // time (FPW == 1), dealt round robin to the workgroups of the launch
+    const long nblocks = (PRECISE && p.frame_list) ? (long)p.frame_list[0] : (long)gridDim.x;
+    for (long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const uint32_t* frames = (PRECISE && p.frame_list) ? p.frame_list + 1 + blk : nullptr;
+    const long f0 = frames ? (long)frames[0] : blk * p.FPW;
+    const int nf = (int)min((long)p.FPW, (long)p.T - f0);
+    __syncthreads();                          // resolver mode: the previous frame's epilogue has read hist / cnt
+    for (int i = tid; i < p.FPW * p.n; i += blockDim.x) {
+        if (PRECISE) ((unsigned long long*)hist)[i] = NO_KEY_BITS; else hist[i] = (HT)0;
+    }
+    for (int i = tid; i < 2 * p.FPW; i += blockDim.x) cnt_chunk[i] = 0;
 
     for (int u0 = 0; u0 < p.U; u0 += p.UC) {
         const int uc = min(p.UC, p.U - u0);
@@ -147,8 +207,8 @@ __global__ void k_spatial_w(const SpatialParams p) {
                     __builtin_amdgcn_wave_barrier();
                     const int t = my_qt[qn + lane];
                     if (PRECISE) {
-                        const double w = fov_weight_exact(my_qc[qn + lane], p.wc);
-                        if (w > 0.0) atomicAdd((double*)&hrow[t], w);
+                        double w;
+                        if (fov_weight_cone(my_qc[qn + lane], p.wc, w)) atomicAdd((double*)&hrow[t], w);
                     } else {
                         const unsigned long long fx = fov_weight_fx<WMODE>(my_qc[qn + lane], p.wc);
                         if (fx) atomicAdd((unsigned long long*)&hrow[t], fx);
@@ -160,8 +220,8 @@ __global__ void k_spatial_w(const SpatialParams p) {
             if (lane < qn) {
                 const int t = my_qt[lane];
                 if (PRECISE) {
-                    const double w = fov_weight_exact(my_qc[lane], p.wc);
-                    if (w > 0.0) atomicAdd((double*)&hrow[t], w);
+                    double w;
+                    if (fov_weight_cone(my_qc[lane], p.wc, w)) atomicAdd((double*)&hrow[t], w);
                 } else {
                     const unsigned long long fx = fov_weight_fx<WMODE>(my_qc[lane], p.wc);
                     if (fx) atomicAdd((unsigned long long*)&hrow[t], fx);
@@ -172,8 +232,12 @@ __global__ void k_spatial_w(const SpatialParams p) {
     }
     __syncthreads();
 
-    weighted_frame_entropy<HT>(hist, cnt_frame, nf, f0, p.n, PRECISE ? 1.0 : 1.0 / (double)(1ull << (52 - p.wc.shift)),
-                               p.hmax, p.ent_k, p.weights, p.present, p.status);
+    if (PRECISE)
+        keyed_frame_entropy((const double*)hist, cnt_frame, nf, f0, p.n, p.hmax, p.ent_k, p.weights, p.present, p.status, frames);
+    else
+        weighted_frame_entropy<HT>(hist, cnt_frame, nf, f0, p.n, 1.0 / (double)(1ull << (52 - p.wc.shift)),
+                                   p.hmax, p.ent_k, p.weights, p.present, p.status);
+    }
     if (p.status) {
         const unsigned long long anybad = __ballot(bad);
         if (anybad && lane == 0) atomicAdd(&p.status[0], (int)__popcll(anybad));

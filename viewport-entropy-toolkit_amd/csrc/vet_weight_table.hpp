@@ -32,6 +32,18 @@ namespace vet {
 // ------------------------------------------------------------------------------------------
 constexpr int TAB_X = 16;       // histogram unit 2^-(32+TAB_X): sums of < 2^16 weights <= 1 fit 64 bits
 
+// The reference's NaN frames (entropy_utils.py:131-135, 195-198).  Every tile with distance < max is a key of the
+// reference's per-frame dict, also when ((max - d) / max) ** power underflows to exactly 0.0; a key whose summed
+// weight w gives fl(w / total) == 0 makes the frame's entropy NaN (0 * log2 0).  With total <= users * tiles < 2^26
+// that needs w < 2^-1048: weights below ULTRA_TINY ("ultra-tiny", exact zeros included) are the only ones that can
+// do it.  Plans that have such (direction, tile) pairs (k_row_stats counts them) never use an integer formulation;
+// their FP table keeps every in-FoV tile whose FP32 entry would be zero — ultra-tiny or merely underflowing below
+// the row's scale — as a MARKER entry (-0.0f: adds nothing), the walk records marker hits in a per-frame bitmap,
+// and a frame with a marked tile whose histogram stayed 0.0 is handed to the precise sweep (exact FP64 weights and
+// the exact key set), which decides NaN / not NaN as the reference does.
+constexpr uint32_t MARKER_BITS = 0x80000000u;            // -0.0f
+#define VET_ULTRA_TINY 0x1p-1048
+
 struct StatsParams {
     const double* dir_unit;
     long D;
@@ -41,9 +53,10 @@ struct StatsParams {
     WeightCfg wc;
     uint8_t* row_s;             // [D+1] TAB_X + e per row (row D = the all-zero row)
     uint16_t* row_e;            // [D+1] E = -(binary exponent of the row's largest weight), unclamped (FP table)
-    unsigned long long* crit;   // [2] bit patterns of non-negative doubles (atomicMax):
+    unsigned long long* crit;   // [3] bit patterns of non-negative doubles (atomicMax):
                                 //   [0] max_d 36.5 q_d k_d / (S_d H_d)   with the table's q_d = 2^(e_d - 33)
                                 //   [1] max_d 36.5 k_d / (S_d H_d)       (times the sweep's step, 2^(shift-53))
+                                //   [2] number of in-FoV (direction, tile) pairs with an ultra-tiny weight (atomicAdd)
 };
 
 __device__ __forceinline__ double wave_max(double v) {
@@ -57,6 +70,7 @@ __global__ void k_row_stats(const StatsParams p) {
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
     double worst_tab = 0.0, worst_sweep = 0.0;
+    int ultra = 0;
     for (long d = wave; d < p.D; d += nwaves) {
         const double dx = p.dir_unit[3 * d], dy = p.dir_unit[3 * d + 1], dz = p.dir_unit[3 * d + 2];
         double S = 0.0, L = 0.0, mx = 0.0;
@@ -67,14 +81,15 @@ __global__ void k_row_stats(const StatsParams p) {
             const int ts = valid ? t : 0;
             const double c = fma(dz, p.tiles[3 * ts + 2], fma(dy, p.tiles[3 * ts + 1], dx * p.tiles[3 * ts]));
             if (valid && c > p.cos_cull) {
-                const double wt = fov_weight_exact(c, p.wc);
+                double wt;
+                if (fov_weight_cone(c, p.wc, wt) && wt < VET_ULTRA_TINY) ++ultra;
                 if (wt > 0.0) { ++k; S += wt; L += wt * log2(wt); mx = fmax(mx, wt); }
             }
         }
         k = wave_sum(k); S = wave_sum(S); L = wave_sum(L); mx = wave_max(mx);
         int e = 0;
         if (mx > 0.0) (void)frexp(mx, &e);                  // mx <= 2^e
-        if (lane == 0) p.row_e[d] = (uint16_t)min(2047, max(0, -e));
+        if (lane == 0) p.row_e[d] = (uint16_t)min(1000, max(0, -e));      // 2^E stays finite; weights below 2^-1048 are markers
         e = min(0, max(-TAB_X, e));
         if (lane == 0) p.row_s[d] = (uint8_t)(TAB_X + e);
         if (k >= 1) {
@@ -86,7 +101,9 @@ __global__ void k_row_stats(const StatsParams p) {
             worst_sweep = fmax(worst_sweep, base);
         }
     }
+    ultra = wave_sum(ultra);
     if (lane == 0) {
+        if (ultra) atomicAdd(&p.crit[2], (unsigned long long)ultra);
         if (p.row_s && wave == 0) { p.row_s[p.D] = (uint8_t)TAB_X; p.row_e[p.D] = 0; }
         if (worst_tab > 0.0) atomicMax(&p.crit[0], (unsigned long long)__double_as_longlong(worst_tab));
         if (worst_sweep > 0.0) atomicMax(&p.crit[1], (unsigned long long)__double_as_longlong(worst_sweep));
@@ -107,6 +124,7 @@ struct WtabParams {
     const uint8_t* row_s;
     const uint16_t* row_e;
     int fp;             // FP table: entries are FP32 weights scaled by 2^E of their row, meta field = E
+    int* markers;       // FP table fill: number of marker entries written (in-FoV tiles without an FP32 value)
     int* maxcount;
     int gs_log2;        // >= 0: well-filled blocks dealt over the 2^gs_log2 lanes of a gather group
 };
@@ -139,7 +157,7 @@ __global__ void k_wtab(const WtabParams p) {
     const int lane = lane_id();
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-    int longest = 0;
+    int longest = 0, nmark = 0;
     for (long d = wave; d < p.D; d += nwaves) {
         const double dx = p.dir_unit[3 * d], dy = p.dir_unit[3 * d + 1], dz = p.dir_unit[3 * d + 2];
         int count = 0;
@@ -154,8 +172,15 @@ __global__ void k_wtab(const WtabParams p) {
             unsigned w32 = 0u;
             if (FILL) {
                 if (hit) {
-                    const double wt = fov_weight_exact(c, p.wc);
-                    w32 = p.fp ? __float_as_uint((float)(wt * scale)) : (unsigned)fmin(rint(wt * scale), 4294967295.0);
+                    double wt;
+                    const bool in_fov = fov_weight_cone(c, p.wc, wt);
+                    if (p.fp) {
+                        // ultra-tiny weights and FP32 underflows become markers: the key survives, the value adds nothing
+                        w32 = wt < VET_ULTRA_TINY ? 0u : __float_as_uint((float)(wt * scale));
+                        if (in_fov && w32 == 0u) { w32 = MARKER_BITS; ++nmark; }
+                    } else {
+                        w32 = (unsigned)fmin(rint(wt * scale), 4294967295.0);
+                    }
                 }
                 hit = w32 != 0u;
             }
@@ -231,6 +256,10 @@ __global__ void k_wtab(const WtabParams p) {
     // a plain read first: the maximum only grows, so most waves find theirs already covered and skip
     // the same-address atomic (2048 of them cost ~100 us)
     if (!FILL && lane == 0 && longest > *(volatile int*)p.maxcount) atomicMax(p.maxcount, longest);
+    if (FILL && p.markers) {
+        nmark = wave_sum(nmark);
+        if (lane == 0 && nmark) atomicAdd(p.markers, nmark);
+    }
     if (FILL && wave == 0) {            // row D: the all-zero row idle lanes of the gather point at
         for (int pos = lane; pos < p.stride; pos += WAVE) {
             p.w[p.D * p.stride + pos] = 0u;

@@ -113,9 +113,38 @@ _lib = None
 _lib_lock = threading.Lock()
 
 
+def _preload_hip_runtime() -> Optional[str]:
+    """One HIP runtime per process.  libvet_hip.so needs ``libamdhip64.so.7``; a PyTorch-ROCm wheel ships its own
+    copy (``torch/lib/libamdhip64.so``, same SONAME) and a process that ends up with both — this library first,
+    ``torch.cuda`` later — fails in torch's ``_cuda_init`` with "No HIP GPUs are available".  So when torch is
+    installed its runtime is loaded first, globally, and the dynamic linker binds libvet_hip.so to it by SONAME
+    (torch is NOT imported; if it already is, this is the runtime it loaded).  ``VET_HIP_RUNTIME=system`` keeps the
+    system runtime.  Returns the path that was preloaded, or None."""
+    if os.environ.get("VET_HIP_RUNTIME", "").lower() == "system":
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if not cand.exists():
+        return None
+    try:
+        C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+    except OSError:
+        return None
+    return str(cand)
+
+
+HIP_RUNTIME_PRELOADED: Optional[str] = None
+
+
 def load_library():
     """dlopen libvet_hip.so and declare every prototype; raises NativeUnavailable."""
-    global _lib
+    global _lib, HIP_RUNTIME_PRELOADED
     with _lib_lock:
         if _lib is not None:
             return _lib
@@ -124,6 +153,7 @@ def load_library():
                 f"HIP extension not found at {LIB_PATH}. Build it with "
                 f"`make -C {_PKG_DIR.parent / 'csrc'}` (or __graft_entry__.build()); "
                 "this package has no CPU compute path.")
+        HIP_RUNTIME_PRELOADED = _preload_hip_runtime()
         try:
             lib = C.CDLL(str(LIB_PATH))
         except OSError as e:  # missing ROCm runtime etc.
@@ -242,9 +272,10 @@ class DeviceResult:
     """Optional outputs of one run, resident in device memory (include/vet.h: vet_result).  ``rows(which, r0, n)``
     copies rows [r0, r0+n) of output ``which`` (0 = assignments / pairs, 1 = weights / source counts)."""
 
-    def __init__(self, lib, handle, n_rows, shapes, dtypes):
+    def __init__(self, lib, handle, n_rows, shapes, dtypes, engine=None):
         self.lib, self.handle, self.n_rows = lib, handle, int(n_rows)
         self.shapes, self.dtypes = shapes, dtypes
+        self.engine = engine           # keeps the device context alive as long as the rows can be fetched
 
     def rows(self, which: int, row0: int, n: int) -> np.ndarray:
         if self.handle is None:
@@ -409,7 +440,7 @@ class Plan:
         h = C.c_void_p()
         rc = self.lib.vet_spatial_entropy_host_resident(self.handle, _ptr(mu), _ptr(mv), _ptr(ids), U, T, _ptr(ent),
                                                         _ptr(present), C.byref(h))
-        result = DeviceResult(self.lib, h, T, [(U,), (self.n_tiles[0],)], [np.int32, np.float64]) if h.value else None
+        result = DeviceResult(self.lib, h, T, [(U,), (self.n_tiles[0],)], [np.int32, np.float64], self.engine) if h.value else None
         if rc not in (VET_OK, VET_ERR_EMPTY, VET_ERR_RANGE) or (check and rc != VET_OK):
             if result is not None:
                 result.close()
@@ -425,7 +456,7 @@ class Plan:
         h = C.c_void_p()
         rc = self.lib.vet_transition_entropy_host_resident(self.handle, _ptr(mu), _ptr(mv), _ptr(ids), U, T, _ptr(ent),
                                                            _ptr(common), C.byref(h))
-        result = DeviceResult(self.lib, h, R, [(U, 2), (self.n_tiles[0],)], [np.int32, np.int32]) if h.value else None
+        result = DeviceResult(self.lib, h, R, [(U, 2), (self.n_tiles[0],)], [np.int32, np.int32], self.engine) if h.value else None
         if rc not in (VET_OK, VET_ERR_EMPTY, VET_ERR_RANGE) or (check and rc != VET_OK):
             if result is not None:
                 result.close()

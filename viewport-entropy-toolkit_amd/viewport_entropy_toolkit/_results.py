@@ -66,10 +66,14 @@ class TileWeights(_RowView):
         self._as_int = as_int
 
     def _mask(self):
+        # dense convention of the C-ABI (include/vet.h): -0.0 = a key of the reference's dict whose value is 0.0
+        # (a tile in some user's FoV whose weight underflowed, entropy_utils.py:131-135), +0.0 = no key
+        if self._row.dtype.kind == "f":
+            return (self._row > 0) | np.signbit(self._row)
         return self._row > 0
 
     def _value(self, i):
-        return int(self._row[i]) if self._as_int else float(self._row[i])
+        return int(self._row[i]) if self._as_int else float(self._row[i]) + 0.0
 
 
 class TileAssignments(_RowView):

@@ -60,7 +60,8 @@ def calculate_tile_weights(vector: Vector, tile_centers: List[Vector], config: E
         if not config.use_weight_distribution:
             return {tile_centers[int(plan.read_nearest(0)[0])]: 1.0}
         row = plan.spatial(ids=np.zeros((1, 1), dtype=np.int32), want_assign=False, want_weights=True)["weights"][0]
-        return {tile_centers[int(i)]: float(row[i]) for i in np.argsort(-row, kind="stable") if row[i] > 0}
+        # -0.0 = in the FoV with a weight that underflowed to 0.0: still a key of the reference's dict
+        return {tile_centers[int(i)]: float(row[i]) + 0.0 for i in np.argsort(-row, kind="stable") if row[i] > 0 or np.signbit(row[i])}
     finally:
         plan.close()
 
@@ -86,7 +87,7 @@ def compute_spatial_entropy(vector_dict: Dict[str, Vector], tile_centers: List[V
     finally:
         plan.close()
     row = res["weights"][0]
-    weights = {tile_centers[int(i)]: float(row[i]) for i in np.nonzero(row > 0)[0]}
+    weights = {tile_centers[int(i)]: float(row[i]) + 0.0 for i in np.nonzero((row > 0) | np.signbit(row))[0]}
     assignments = {k: int(a) for (k, _), a in zip(users, res["assign"][0])}
     return float(res["entropy"][0]), weights, assignments
 
