@@ -142,7 +142,8 @@ int64_t vet_plan_n_dirs(const vet_plan *plan);
  * Which formulation a call uses is a pure function of the plan and the call's shape, never of the
  * plan's history: policy 0 = table iff the call (or batch) holds >= 8 samples per direction of the
  * plan's direction table, +1 = table whenever it is inside the contract and fits, -1 = never table.
- * vet_plan_table_stride: row length of lattice k's table, 0 = not built (yet), -1 = does not fit.
+ * vet_plan_table_stride: row length of lattice k's table (of the plan's fused table — one row per direction over
+ * all lattices — where that is the one in use), 0 = not built (yet), -1 = does not fit.
  * vet_plan_last_formulation: formulation lattice k used in the plan's last weighted call (-1 none).
  * vet_plan_error_bounds: the proven relative entropy error bounds of lattice k for the table and the
  * sweep (at <= 1024 users) formulations; inf = a frame exists whose entropy no fixed point resolves. */

@@ -253,3 +253,54 @@ def test_batch_of_videos_in_one_launch(native, engine, policy):
         ent, assign, _ = vo.spatial_series(mu, mv, 100, 200, [50, 100])
         np.testing.assert_allclose(g["entropy"], ent, rtol=1e-8)
     plan.close()
+
+
+def _fused_variants_worker(q, env):
+    """Child process: the same plans through the fused table's other kernels, selected by environment."""
+    import os
+    os.environ.update(env)
+    from viewport_entropy_toolkit import _native, _synthetic
+    eng = _native.Engine(0)
+    out = {}
+    for name, tcs, U, T in FUSED_CASES:
+        mu, mv = _synthetic.random_walk_video(U, T, base_seed=17, p_absent=0.1)
+        plan = _native.Plan(eng, [vo.fibonacci_lattice(tc) for tc in tcs], 120.0, 2.0, True, 100, 200)
+        plan.set_table_policy(1)
+        r = plan.spatial(mu=mu, mv=mv, want_weights=True)
+        out[name] = (r["entropy"], r["assign"], r["weights"], plan.last_formulation(0))
+        plan.close()
+    q.put(out)
+
+
+FUSED_CASES = (("k1", [500], 96, 700), ("k3", [50, 100, 200], 200, 900), ("k5", [20, 50, 100, 250, 1000], 64, 300))
+
+
+@pytest.mark.parametrize("env", [{"VET_ROWS": "1"}, {"VET_FUSED": "1"}, {"VET_NO_FUSED": "1"}])
+def test_fused_table_kernels_agree(env):
+    """The fused table (one row per distinct direction over all lattices) through k_spatial_lut, through the
+    persistent k_spatial_rows (experimental, VET_ROWS=1) and the per-lattice tables (VET_NO_FUSED=1): the two fused
+    kernels are bit-identical to each other (exact totals, canonical summation order) and all agree with the oracle."""
+    import multiprocessing as mp
+    from viewport_entropy_toolkit import _synthetic
+    ctx = mp.get_context("spawn")
+    res = []
+    for e in ({}, env):
+        q = ctx.Queue()
+        p = ctx.Process(target=_fused_variants_worker, args=(q, e))
+        p.start()
+        res.append(q.get(timeout=600))
+        p.join(60)
+        assert p.exitcode == 0
+    for name, tcs, U, T in FUSED_CASES:
+        a, b = res[0][name], res[1][name]
+        assert a[3] == b[3] == "table"
+        assert np.array_equal(a[1], b[1])
+        if "VET_NO_FUSED" in env or name == "k1":
+            np.testing.assert_allclose(b[0], a[0], rtol=1e-12, equal_nan=True)
+        else:
+            assert np.array_equal(a[0], b[0], equal_nan=True), name          # fused k_spatial_lut == k_spatial_rows, bit for bit
+        np.testing.assert_allclose(b[2], a[2], rtol=0, atol=2.0 ** -33 * U)
+        mu, mv = _synthetic.random_walk_video(U, T, base_seed=17, p_absent=0.1)
+        ent, assign, _ = vo.spatial_series(mu[:60], mv[:60], 100, 200, tcs)
+        assert np.array_equal(b[1][:60], assign)
+        np.testing.assert_allclose(b[0][:60], ent, rtol=1e-8, equal_nan=True)

@@ -58,7 +58,8 @@ def test_g12_nan_pattern_and_keys(native, engine, golden_dir, tc, fov, power, po
     np.testing.assert_allclose(res["entropy"][ok], ref[ok], rtol=1e-6, atol=1e-15)
     if form in ("ftable", "precise"):                  # the FP64 formulations keep the reference's key set exactly
         assert np.array_equal(keys_of(res["weights"]), g[f"{tag}__keys"]), form
-        np.testing.assert_allclose(np.abs(res["weights"]), g[f"{tag}__hist"], rtol=2e-7 if form == "ftable" else 1e-9, atol=0)
+        np.testing.assert_allclose(np.abs(res["weights"]), g[f"{tag}__hist"], rtol=2e-7 if form == "ftable" else 1e-9,
+                                   atol=8 * 2.0 ** -149 if form == "ftable" else 0)     # FP32 entries below 2^-126 of their row's scale are denormal
     else:
         np.testing.assert_allclose(res["weights"], g[f"{tag}__hist"], rtol=1e-9, atol=2.0 ** -33 * 8)
     plan.close()
@@ -92,7 +93,7 @@ def test_resolver_on_crowded_frames(native, engine, tcs, fov, power, U, policy):
     ok = ~np.isnan(ent)
     np.testing.assert_allclose(a["entropy"][ok], ent[ok], rtol=1e-6, atol=1e-15)
     assert np.array_equal(keys_of(a["weights"]), keys_of(weights))
-    np.testing.assert_allclose(np.abs(a["weights"]), np.abs(weights), rtol=2e-7 if policy > 0 else 1e-9, atol=0)
+    np.testing.assert_allclose(np.abs(a["weights"]), np.abs(weights), rtol=2e-7 if policy > 0 else 1e-9, atol=U * 2.0 ** -149 if policy > 0 else 0)
     plan.close()
 
 

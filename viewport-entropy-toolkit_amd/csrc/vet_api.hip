@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <algorithm>
 #include <array>
 #include <string>
 #include <unordered_map>
@@ -128,6 +129,22 @@ struct vet_plan {
     uint32_t* d_alias = nullptr;   // [n_dirs] direction id -> table row | mirrored << 31 (ensure_alias)
     bool mirror = false;           // rows are shared between mirror-image directions
     uint2* d_dirrec = nullptr;     // [n_dirs] alias | nearest tile | lattice-0 row meta (k_dirrec), dedup-capable plans
+    std::vector<uint32_t> h_alias; // host copy of d_alias
+    // fused table of k_spatial_rows (vet_spatial_rows.hpp): one row per distinct direction over ALL lattices
+    struct Fused {
+        int state = 0;             // 0 not built, 1 ready, -1 not usable for this plan
+        int R = 0, stride = 0, gs_log2 = 4;
+        bool interleaved = false;
+        vet::FusedLayout lay;
+        int* d_canon = nullptr;    // [R] row -> direction
+        uint32_t* d_rec = nullptr; // [n_dirs] direction -> row | mirrored << 15 | nearest tile << 16
+        uint16_t* d_lens = nullptr;// [R+2]
+        uint32_t* d_meta = nullptr;// [R+1] entries in use | row shift << 16 (k_spatial_lut's form of lens)
+        uint2* d_dirrec = nullptr; // [n_dirs] k_spatial_lut's per-direction record over the fused rows (k_dirrec)
+        uint8_t* d_row_s = nullptr;// [R+1] fused row shifts
+        uint32_t* d_w = nullptr;   // [R+1][stride]
+        uint16_t* d_i = nullptr;   // [R+1][stride]
+    } fused;
     bool stats_all = false;        // k_row_stats has run for every weighted lattice
     bool ultra = false;            // some lattice has ultra-tiny in-FoV weights: FP64 formulations only (plan-wide)
 };
@@ -265,6 +282,15 @@ const void* spatial_w_kernel(int wmode, int R, bool precise = false) {
 }
 
 template <bool FROM_IDS>
+const void* lut_kernel_fused(bool il, bool occ8, bool dedup) {
+#define VET_PICK(I, O, D) if (il == I && occ8 == O && dedup == D) return (const void*)vet::k_spatial_lut<FROM_IDS, 2, I, O, D, false, true>
+    VET_PICK(false, false, false); VET_PICK(false, true, false); VET_PICK(true, false, false); VET_PICK(true, true, false);
+    VET_PICK(false, false, true); VET_PICK(false, true, true); VET_PICK(true, false, true); VET_PICK(true, true, true);
+#undef VET_PICK
+    return nullptr;
+}
+
+template <bool FROM_IDS>
 const void* lut_kernel(bool il, bool occ8, bool dedup, bool fpt = false) {
     if (fpt) {      // FP table: 7 workgroups per CU (FP64 scale registers)
 #define VET_PICKF(I, D) if (il == I && dedup == D) return (const void*)vet::k_spatial_lut<FROM_IDS, 2, I, false, D, true>
@@ -345,6 +371,7 @@ int ensure_alias(vet_plan* pl) {
         return fail(VET_ERR_DEVICE, "alias table upload failed: %s", hipGetErrorString(e));
     }
     pl->d_alias = d_alias;
+    pl->h_alias = std::move(alias);
     return VET_OK;
 }
 
@@ -361,7 +388,7 @@ int ensure_stats(vet_plan* pl, int k, hipStream_t s) {
         return fail(VET_ERR_DEVICE, "hipMalloc of the row shift table failed");
     }
     hipError_t e = hipMemsetAsync(d_crit, 0, 24, s);
-    vet::StatsParams p;
+    vet::StatsParams p{};
     p.dir_unit = pl->d_dir_unit; p.D = (long)pl->n_dirs;
     p.tiles = L.d_tiles; p.n = L.n;
     p.cos_cull = pl->cos_cull;
@@ -415,7 +442,7 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     HIP_TRY(hipMalloc((void**)&d_max, 2 * sizeof(int)));
     struct FreeMax { int* p; ~FreeMax() { (void)hipFree(p); } } free_max{d_max};
     hipError_t e = hipMemsetAsync(d_max, 0, 2 * sizeof(int), s);
-    vet::WtabParams p;
+    vet::WtabParams p{};
     p.dir_unit = pl->d_dir_unit; p.D = (long)pl->n_dirs;
     p.tiles = L.d_tiles; p.n = L.n;
     p.cos_cull = pl->cos_cull;
@@ -490,6 +517,210 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     return VET_OK;
 }
 
+bool any_binned(const vet_plan* pl);
+int rows_chunks(const vet::FusedLayout& lay) {         // 64-tile chunks of the largest lattice
+    int ch = 1;
+    for (int k = 0; k < lay.K; ++k) ch = std::max(ch, (lay.n[k] + 63) / 64);
+    return ch;
+}
+constexpr size_t kRowsLdsCap = 160 * 1024 - 512;      // k_spatial_rows: one workgroup per CU takes the whole LDS
+
+// Builds the plan's fused table (first use; synchronises).  state = -1: the plan stays on k_spatial_lut.
+int ensure_fused(vet_plan* pl, hipStream_t s) {
+    auto& F = pl->fused;
+    if (F.state != 0) return VET_OK;
+    F.state = -1;
+    vet_ctx* c = pl->ctx;
+    const int K = (int)pl->lat.size();
+    // one lattice: a fused row is the lattice's own row — nothing to share, and the per-lattice epilogue is a little
+    // cheaper (clustered audience, config-3 shape: 0.48 vs 0.51 ms); VET_FUSED=1 / VET_ROWS=1 fuse such plans too
+    if (K == 1 && !getenv("VET_FUSED") && !getenv("VET_ROWS")) return VET_OK;
+    if (!pl->weighted || K > vet::MAX_LATTICES || any_binned(pl) || getenv("VET_NO_FUSED")) return VET_OK;
+    if ((uint64_t)pl->n_dirs > vet::DEDUP_MAX_DIRS) return VET_OK;
+    int rc = ensure_all_stats(pl, s);
+    if (rc) return rc;
+    if (pl->ultra) return VET_OK;
+    for (const auto& L : pl->lat)
+        if (!(L.crit_tab <= kContractMargin) || !L.d_row_s) return VET_OK;
+    rc = ensure_alias(pl);
+    if (rc) return rc;
+    const size_t D = (size_t)pl->n_dirs;
+    // canonical rows, densely numbered
+    std::vector<int> canon;
+    std::vector<uint32_t> rowid(D, 0u), rowsel(D);
+    for (size_t d = 0; d < D; ++d)
+        if (pl->h_alias[d] == (uint32_t)d) { rowid[d] = (uint32_t)canon.size(); canon.push_back((int)d); }
+    const int R = (int)canon.size();
+    if (R == 0) return VET_OK;
+    for (size_t d = 0; d < D; ++d) rowsel[d] = rowid[pl->h_alias[d] & 0x7FFFFFFFu] | (pl->h_alias[d] & 0x80000000u);
+    vet::FusedLayout& lay = F.lay;
+    lay.K = K; lay.Hs = 0; lay.CF = 0;
+    for (int k = 0; k < K; ++k) {
+        lay.n[k] = pl->lat[k].n; lay.off[k] = 2 * K + lay.Hs; lay.Hs += pl->lat[k].n >> 1; lay.hmax[k] = pl->lat[k].hmax;
+        lay.CF += (pl->lat[k].n + vet::WAVE - 1) / vet::WAVE;
+    }
+    lay.N = 2 * (lay.Hs + K) + 4 * K;
+    lay.totals = getenv("VET_ROWS") ? 1 : 0;      // k_spatial_rows (experimental) wants the total slots; same-address LDS atomics cost k_spatial_lut 12 %
+    if (lay.N > 65535 || lay.N < 32) return VET_OK;
+
+    DevBuf rowsel_d, ptrs_d, delta_d, max_d;
+    HIP_TRY(rowsel_d.alloc(D * 4));
+    HIP_TRY(ptrs_d.alloc(sizeof(void*) * vet::MAX_LATTICES));
+    HIP_TRY(delta_d.alloc(sizeof(int) * vet::MAX_LATTICES));
+    HIP_TRY(max_d.alloc(sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&F.d_canon, (size_t)R * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&F.d_rec, D * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&F.d_row_s, (size_t)R + 1));
+    HIP_TRY(hipMemcpyAsync(F.d_canon, canon.data(), (size_t)R * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(rowsel_d.p, rowsel.data(), D * 4, hipMemcpyHostToDevice, s));
+    const uint8_t* ptrs[vet::MAX_LATTICES] = {};
+    for (int k = 0; k < K; ++k) ptrs[k] = pl->lat[k].d_row_s;
+    HIP_TRY(hipMemcpyAsync(ptrs_d.p, ptrs, sizeof(ptrs), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(delta_d.p, 0, sizeof(int) * vet::MAX_LATTICES, s));
+    HIP_TRY(hipMemsetAsync(max_d.p, 0, sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(F.d_row_s + R, vet::TAB_X, 1, s));
+    hipLaunchKernelGGL(vet::k_rowrec, dim3(grid_for((long)D, 256, c->n_cu)), dim3(256), 0, s, (const uint32_t*)rowsel_d.p,
+                       (const uint16_t*)pl->lat[0].d_nearest, (long)D, F.d_rec);
+    hipLaunchKernelGGL(vet::k_fuse_shifts, dim3(grid_for(R, 256, c->n_cu)), dim3(256), 0, s, (const int*)F.d_canon, R, K,
+                       (const uint8_t* const*)ptrs_d.p, F.d_row_s, (int*)delta_d.p);
+    vet::WtabParams p{};
+    p.dir_unit = pl->d_dir_unit; p.D = R;
+    p.tiles = nullptr; p.n = 0;
+    p.cos_cull = pl->cos_cull;
+    p.wc.max_ang = pl->max_ang; p.wc.inv_max = 1.0 / pl->max_ang; p.wc.power = pl->power; p.wc.shift = 0;
+    p.stride = 0; p.w = nullptr; p.idx = nullptr; p.meta = nullptr; p.row_s = F.d_row_s; p.row_e = nullptr; p.fp = 0;
+    p.markers = nullptr; p.maxcount = (int*)max_d.p; p.gs_log2 = -1;
+    p.canon = F.d_canon; p.nl = K; p.Hs = lay.Hs; p.N = lay.N; p.totals = lay.totals; p.lens = nullptr;
+    for (int k = 0; k < 8; ++k) { p.tiles_v[k] = k < K ? pl->lat[k].d_tiles : nullptr; p.n_v[k] = k < K ? lay.n[k] : 0; p.off_v[k] = k < K ? lay.off[k] : 0; }
+    const int blocks = grid_for((long)R * vet::WAVE, 256, c->n_cu * 2);
+    {
+        ProfScope ps(c, s, KID_WTAB);
+        hipLaunchKernelGGL(vet::k_wtab<false>, dim3(blocks), dim3(256), 0, s, p);
+    }
+    int longest = 0, delta[vet::MAX_LATTICES] = {};
+    HIP_TRY(hipMemcpyAsync(&longest, max_d.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(delta, delta_d.p, sizeof(delta), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // a shared shift is coarser than a lattice's own where delta[k] > 0: that lattice's error bound is evaluated
+    // again with the rows' shared shifts (k_row_stats, fused pass)
+    for (int k = 0; k < K; ++k) {
+        if (delta[k] == 0) continue;
+        DevBuf crit;
+        HIP_TRY(crit.alloc(24));
+        HIP_TRY(hipMemsetAsync(crit.p, 0, 24, s));
+        vet::StatsParams sp{};
+        sp.dir_unit = pl->d_dir_unit; sp.D = R;
+        sp.tiles = pl->lat[k].d_tiles; sp.n = pl->lat[k].n;
+        sp.cos_cull = pl->cos_cull;
+        sp.wc.max_ang = pl->max_ang; sp.wc.inv_max = 1.0 / pl->max_ang; sp.wc.power = pl->power; sp.wc.shift = 0;
+        sp.row_s = nullptr; sp.row_e = nullptr; sp.crit = (unsigned long long*)crit.p;
+        sp.canon = F.d_canon; sp.shift_in = F.d_row_s;
+        hipLaunchKernelGGL(vet::k_row_stats, dim3(grid_for((long)R * vet::WAVE, 256, c->n_cu * 2)), dim3(256), 0, s, sp);
+        unsigned long long bits = 0;
+        HIP_TRY(hipMemcpyAsync(&bits, crit.p, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        double bound = 0.0;
+        memcpy(&bound, &bits, 8);
+        if (!(bound <= kContractMargin)) return VET_OK;
+    }
+    if (longest >= (1 << vet::ROWS_LEN_BITS)) return VET_OK;
+    const int stride = ((longest > 0 ? longest : 1) + 63) / 64 * 64;
+    const size_t rows = (size_t)R + 1;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = kMaxTableBytes;
+    const size_t bytes = rows * stride * 6;
+    if (bytes > kMaxTableBytes || rows * (size_t)stride >= ((size_t)1 << 32) || bytes + ((size_t)64 << 20) > free_b) return VET_OK;
+    if (hipMalloc((void**)&F.d_w, rows * stride * 4) != hipSuccess || hipMalloc((void**)&F.d_i, rows * stride * 2) != hipSuccess ||
+        hipMalloc((void**)&F.d_lens, (rows + 1) * 2) != hipSuccess || hipMalloc((void**)&F.d_meta, rows * 4) != hipSuccess ||
+        hipMalloc((void**)&F.d_dirrec, D * sizeof(uint2)) != hipSuccess) {
+        (void)hipGetLastError();
+        return VET_OK;
+    }
+    F.gs_log2 = 1;
+    while (F.gs_log2 < 4 && (4 << F.gs_log2) < longest) ++F.gs_log2;
+    F.interleaved = F.gs_log2 == 4 && 4 * longest >= 3 * 64 && env_int("VET_TAB_INTERLEAVE", 0, 1, 1) != 0;
+    p.stride = stride; p.w = F.d_w; p.idx = F.d_i; p.lens = F.d_lens; p.meta = F.d_meta; p.maxcount = nullptr;
+    p.gs_log2 = F.interleaved ? F.gs_log2 : -1;
+    {
+        ProfScope ps(c, s, KID_WTAB);
+        hipLaunchKernelGGL(vet::k_wtab<true>, dim3(blocks), dim3(256), 0, s, p);
+    }
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(vet::k_dirrec, dim3(grid_for((long)D, 256, c->n_cu)), dim3(256), 0, s, (const uint32_t*)rowsel_d.p,
+                       (const uint16_t*)pl->lat[0].d_nearest, (const uint32_t*)F.d_meta, (long)D, F.d_dirrec);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    F.R = R; F.stride = stride;
+    F.state = 1;
+    return VET_OK;
+}
+
+// frames per round of k_spatial_rows for frames of U users (0: does not fit); rounds evened out over the CUs
+int rows_frames_per_round(const vet_plan* pl, int U, long T, int n_cu, int* hs_out) {
+    const auto& F = pl->fused;
+    if (F.state != 1 || U > 2048 || !pl->grid || F.R > 32767 || !getenv("VET_ROWS")) return 0;   // experimental
+    int HS = 64;
+    while (HS < 2 * U) HS <<= 1;
+    *hs_out = HS;
+    int fb = (vet::ROWS_SPT * vet::ROWS_THREADS) / U;
+    if (fb > 16) fb = 16;
+    const size_t fixed = vet::rows_lds_static((int)pl->n_dirs, F.R);
+    while (fb > 0 && fixed + vet::rows_lds_round(fb, HS, U, F.lay.N, F.lay.CF) > kRowsLdsCap) --fb;
+    if (fb <= 0) return 0;
+    fb = env_int("VET_ROWS_FB", 1, fb, fb);
+    if (T > 0) {                         // same number of rounds for every workgroup where possible
+        const long rounds = (T + fb - 1) / fb, per_wg = (rounds + n_cu - 1) / n_cu;
+        long even = (T + per_wg * n_cu - 1) / (per_wg * n_cu);
+        if (even >= 1 && even <= fb) fb = (int)even;
+    }
+    return fb;
+}
+
+const void* rows_kernel(bool il, int un) {
+    if (un >= 4) return il ? (const void*)vet::k_spatial_rows<true, 4> : (const void*)vet::k_spatial_rows<false, 4>;
+    return il ? (const void*)vet::k_spatial_rows<true, 2> : (const void*)vet::k_spatial_rows<false, 2>;
+}
+
+// one launch of k_spatial_rows (single video, or a batch whose descriptors carry block0 = first round)
+int launch_rows(vet_plan* pl, const double* mu, const double* mv, int U, int T, const vet::VideoDesc* d_videos, int n_videos,
+                long n_rounds, int FB, int HS, int ucap, double* d_entropy, int32_t* d_assign, double* d_weights,
+                int32_t* d_present, int32_t* d_status, hipStream_t s) {
+    vet_ctx* c = pl->ctx;
+    const auto& F = pl->fused;
+    vet::RowsParams q{};
+    q.videos = d_videos; q.n_videos = n_videos;
+    q.mu = mu; q.mv = mv; q.U = U; q.T = T; q.W = pl->W; q.H = pl->H;
+    q.rec = F.d_rec; q.lens = F.d_lens; q.D = (int)pl->n_dirs; q.R = F.R;
+    q.tab_w = F.d_w; q.tab_i = F.d_i; q.stride = F.stride; q.gs_log2 = F.gs_log2; q.interleaved = F.interleaved ? 1 : 0;
+    q.lay = F.lay;
+    q.entropy = d_entropy; q.assign = d_assign; q.weights = d_weights; q.present = d_present; q.status = d_status;
+    q.FB = FB; q.HS = HS; q.UCAP = ucap; q.n_rounds = n_rounds;
+    const size_t lds = vet::rows_lds_static(q.D, q.R) + vet::rows_lds_round(FB, HS, ucap, F.lay.N, F.lay.CF);
+    long grid = c->n_cu;
+    if (grid > n_rounds) grid = n_rounds;
+    DevBuf dbg;
+    if (getenv("VET_ROWS_DEBUG")) {          // development aid: cycles per phase (wave 0 of every workgroup), synchronous
+        HIP_TRY(dbg.alloc(64));
+        HIP_TRY(hipMemsetAsync(dbg.p, 0, 64, s));
+        q.dbg = (unsigned long long*)dbg.p;
+    }
+    {
+        ProfScope ps(c, s, KID_SPATIAL);
+        void* args[] = {(void*)&q};
+        const void* fn = rows_kernel(F.interleaved, env_int("VET_ROWS_UN", 1, 4, 4));
+        HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(vet::ROWS_THREADS), args, lds, s));
+        HIP_TRY(hipGetLastError());
+    }
+    if (dbg.p) {
+        unsigned long long t[8] = {};
+        HIP_TRY(hipMemcpyAsync(t, dbg.p, 64, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        fprintf(stderr, "[k_spatial_rows] grid %ld FB %d rounds %ld | cycles per workgroup (wave 0): loop %.0f  entropy %.0f  walk+own samples %.0f  late samples %.0f  barrier %.0f  - %.0f\n",
+                grid, FB, n_rounds, (double)t[0] / grid, (double)t[1] / grid, (double)t[2] / grid, (double)t[3] / grid, (double)t[4] / grid, (double)t[5] / grid);
+    }
+    return VET_OK;
+}
+
 // Frames per workgroup of the table kernel: about 1024 samples per workgroup, at most one frame per
 // wave (the epilogue reduces a frame per wave, and every frame costs n_sum * 8 B of LDS), and never
 // so many that the launch has fewer than ~4 workgroups per CU (measured: config 4 best at 4 frames
@@ -504,6 +735,12 @@ int lut_frames_per_wg(int U, long total_frames, int n_cu, int n_sum) {
     while (2 * fpw <= f) fpw *= 2;
     // keep ~7 workgroups per CU resident: at most ~20 KB of LDS histograms per workgroup
     while (fpw > 1 && (size_t)fpw * n_sum * 8 > 20 * 1024) fpw /= 2;
+    // the launch runs in waves of 8 workgroups per CU: fewer frames per workgroup where that shortens the tail
+    // (config 4: 2 500 workgroups of 4 frames = 2 waves x 4 frames; 10 000 of 1 frame = 5 x 1; measured 0.175 -> 0.163 ms)
+    const long slots = 8L * n_cu;
+    auto cost = [&](int f) { const long wgs = (total_frames + f - 1) / f; return (double)((wgs + slots - 1) / slots) * (f + 0.35); };
+    for (int f = fpw / 2; f >= 1; f /= 2)
+        if (cost(f) < cost(fpw)) fpw = f;
     return fpw;
 }
 
@@ -564,7 +801,7 @@ int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& sr
                hipStream_t s, bool* launched, uint32_t* d_resolve = nullptr) {
     vet_ctx* c = pl->ctx;
     *launched = false;
-    vet::LutParams q;
+    vet::LutParams q{};
     q.resolve = d_resolve;
     q.videos = d_videos; q.n_videos = n_videos;
     q.src = src; q.U = U; q.T = T;
@@ -581,6 +818,7 @@ int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& sr
         q.lat[k].stride = L.stride;
         q.lat[k].gs_log2 = L.gs_log2; q.lat[k].interleaved = L.interleaved ? 1 : 0;
         q.lat[k].n = L.n; q.lat[k].hmax = L.hmax;
+        q.lat[k].zrow = (uint32_t)pl->n_dirs;
         q.n_sum += L.n;
         il = il || L.interleaved;
     }
@@ -616,6 +854,66 @@ int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& sr
     // 2 rows in flight per lane group measured best (4 and 8 were tried, profiles/r01/v3_*)
     HIP_TRY(hipLaunchKernel(lut_kernel<FROM_IDS>(il, occ8 && !fpt, dedup, fpt), dim3((unsigned)blocks), dim3(threads), args, lds, s));
     HIP_TRY(hipGetLastError());
+    *launched = true;
+    return VET_OK;
+}
+
+// k_spatial_lut over the plan's fused table (single video, or a batch): the kernel sees ONE lattice of N slots
+template <bool FROM_IDS>
+int launch_lut_fused(vet_plan* pl, const vet::SampleSrc& src, int U, int T, const vet::VideoDesc* d_videos, int n_videos,
+                     int blocks_batch, size_t lds_batch, int batch_max_users, double* d_entropy, int32_t* d_assign,
+                     double* d_weights, int32_t* d_present, int32_t* d_status, hipStream_t s, bool* launched) {
+    vet_ctx* c = pl->ctx;
+    const auto& F = pl->fused;
+    *launched = false;
+    vet::LutParams q{};
+    q.videos = d_videos; q.n_videos = n_videos;
+    q.src = src; q.U = U; q.T = T;
+    q.nearest = pl->lat[0].d_nearest; q.alias = nullptr; q.dirrec = F.d_dirrec; q.rec_meta = 1;
+    q.K = 1; q.n_sum = F.lay.N;
+    q.lat[0].tab_w = F.d_w; q.lat[0].tab_i = F.d_i; q.lat[0].tab_meta = F.d_meta;
+    q.lat[0].stride = F.stride; q.lat[0].gs_log2 = F.gs_log2; q.lat[0].interleaved = F.interleaved ? 1 : 0;
+    q.lat[0].n = F.lay.N; q.lat[0].hmax = 0.0; q.lat[0].zrow = (uint32_t)F.R;
+    q.lay = F.lay;
+    q.entropy = d_entropy; q.assign = d_assign; q.weights = d_weights; q.present = d_present; q.status = d_status;
+    const int dedup_users = env_int("VET_DEDUP_MIN_USERS", 1, 1 << 20, 128);
+    const bool dedup = !getenv("VET_NO_DEDUP") && (d_videos ? batch_max_users : U) >= dedup_users;
+    int blocks = blocks_batch, threads = 256;
+    size_t lds = lds_batch;
+    if (!d_videos) {
+        q.UC = U < 2048 ? U : 2048;
+        int fpw = lut_frames_per_wg(U, T, c->n_cu, q.n_sum);
+        fpw = env_int("VET_LUT_FPW", 1, 16, fpw);
+        for (;; fpw /= 2) {
+            lds = vet::lut_lds_bytes(U, q.UC, fpw, q.n_sum, dedup);
+            if (lds <= c->lds_max || fpw == 1) break;
+        }
+        if (lds > c->lds_max) return VET_OK;      // not launched: the caller falls back
+        q.FPW = fpw;
+        blocks = (T + fpw - 1) / fpw;
+    } else {
+        q.FPW = 1; q.UC = 1;
+    }
+    const bool occ8 = env_int("VET_LUT_OCC8", 0, 1, 1) != 0;
+    DevBuf dbg;
+    if (getenv("VET_LUT_DEBUG")) {           // development aid: cycles per stage (thread 0 of every workgroup), synchronous
+        HIP_TRY(dbg.alloc(32));
+        HIP_TRY(hipMemsetAsync(dbg.p, 0, 32, s));
+        q.dbg = (unsigned long long*)dbg.p;
+    }
+    {
+        ProfScope ps(c, s, KID_SPATIAL);
+        void* args[] = {(void*)&q};
+        HIP_TRY(hipLaunchKernel(lut_kernel_fused<FROM_IDS>(F.interleaved, occ8, dedup), dim3((unsigned)blocks), dim3(threads), args, lds, s));
+        HIP_TRY(hipGetLastError());
+    }
+    if (dbg.p) {
+        unsigned long long t[4] = {};
+        HIP_TRY(hipMemcpyAsync(t, dbg.p, 32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        fprintf(stderr, "[k_spatial_lut fused] blocks %d FPW %d lds %zu | cycles per workgroup (thread 0): samples->set %.0f  lists %.0f  walk %.0f  entropy %.0f\n",
+                blocks, q.FPW, lds, (double)t[0] / blocks, (double)t[1] / blocks, (double)t[2] / blocks, (double)t[3] / blocks);
+    }
     *launched = true;
     return VET_OK;
 }
@@ -660,7 +958,7 @@ int resolve_frames(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc
         Geometry g;
         int rc = spatial_geometry(c, L.n, U, true, &g, true);
         if (rc) return rc;
-        vet::SpatialParams p;
+        vet::SpatialParams p{};
         p.src = src; p.U = U; p.T = T;
         p.dir_unit = pl->d_dir_unit; p.nearest = L.d_nearest; p.tiles = L.d_tiles; p.n = L.n;
         p.cos_cull = pl->cos_cull;
@@ -697,6 +995,27 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
     int form[64];
     if (K > 64) return fail(VET_ERR_UNSUPPORTED, "more than 64 lattices in one plan");
     const bool want_table = table_requested(pl, (long)U * T, U);
+    // ---- weighted, integer table formulation on fused rows (k_spatial_rows): persistent workgroups, the direction
+    // records in LDS, one row per distinct direction over all lattices — where the plan allows (ensure_fused)
+    if (want_table && pl->weighted) {
+        int rc = ensure_fused(pl, s);
+        if (rc) return rc;
+        int HS = 0;
+        const int fb = FROM_IDS ? 0 : rows_frames_per_round(pl, U, T, c->n_cu, &HS);
+        if (fb > 0) {
+            rc = launch_rows(pl, src.mu, src.mv, U, T, nullptr, 0, ((long)T + fb - 1) / fb, fb, HS, U, d_entropy, d_assign,
+                             d_weights, d_present, d_status, s);
+            if (!rc) for (int k = 0; k < K; ++k) pl->lat[k].last_form = F_TABLE;
+            return rc;
+        }
+        if (pl->fused.state == 1) {
+            bool launched = false;
+            rc = launch_lut_fused<FROM_IDS>(pl, src, U, T, nullptr, 0, 0, 0, 0, d_entropy, d_assign, d_weights, d_present,
+                                            d_status, s, &launched);
+            if (launched) for (int k = 0; k < K; ++k) pl->lat[k].last_form = F_TABLE;
+            if (rc || launched) return rc;
+        }
+    }
     bool all_table = pl->weighted != 0;
     for (int k = 0; k < K; ++k) {
         form[k] = F_SWEEP;
@@ -754,7 +1073,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         Geometry g;
         int rc = spatial_geometry(c, L.n, U, hist_weighted, &g);
         if (rc) return rc;
-        vet::SpatialParams p;
+        vet::SpatialParams p{};
         p.src = src;
         p.U = U; p.T = T;
         p.dir_unit = pl->d_dir_unit;
@@ -855,7 +1174,7 @@ int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, dou
         const size_t lds_cap = 160 * 1024 - 512;     // a single workgroup may take the whole LDS
         if (lds_tiles > lds_cap)
             return fail(VET_ERR_UNSUPPORTED, "transition kernel: %d tiles need %zu B of LDS (max %zu)", L.n, lds_tiles, lds_cap);
-        vet::TransParams p;
+        vet::TransParams p{};
         p.src = src;
         p.U = U; p.T = T;
         p.nearest = L.d_nearest;
@@ -1153,6 +1472,8 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
         PLAN_TRY(hipFuncSetAttribute(spatial_w_kernel<true>(0, R, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     }
     for (int v = 0; v < 8; ++v) {
+        PLAN_TRY(hipFuncSetAttribute(lut_kernel_fused<false>(v & 1, v & 2, v & 4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+        PLAN_TRY(hipFuncSetAttribute(lut_kernel_fused<true>(v & 1, v & 2, v & 4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
         PLAN_TRY(hipFuncSetAttribute(lut_kernel<false>(v & 1, v & 2, v & 4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
         PLAN_TRY(hipFuncSetAttribute(lut_kernel<true>(v & 1, v & 2, v & 4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
         if (!(v & 2)) {
@@ -1160,6 +1481,9 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
             PLAN_TRY(hipFuncSetAttribute(lut_kernel<true>(v & 1, false, v & 4, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
         }
     }
+    for (int un : {2, 4})
+        for (int il = 0; il < 2; ++il)
+            PLAN_TRY(hipFuncSetAttribute(rows_kernel(il != 0, un), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowsLdsCap));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
@@ -1200,6 +1524,11 @@ int vet_plan_destroy(vet_plan* pl) {
     }
     if (pl->d_alias) (void)hipFree(pl->d_alias);
     if (pl->d_dirrec) (void)hipFree(pl->d_dirrec);
+    {
+        auto& F = pl->fused;
+        for (void* q : {(void*)F.d_canon, (void*)F.d_rec, (void*)F.d_lens, (void*)F.d_row_s, (void*)F.d_w, (void*)F.d_i, (void*)F.d_meta, (void*)F.d_dirrec})
+            if (q) (void)hipFree(q);
+    }
     delete pl;
     return VET_OK;
 }
@@ -1214,6 +1543,8 @@ int vet_plan_set_table_policy(vet_plan* pl, int policy) {
 
 int vet_plan_table_stride(const vet_plan* pl, int k) {
     if (!pl || k < 0 || k >= (int)pl->lat.size()) return 0;
+    // plans on the fused table (one row per direction over all lattices) never build the per-lattice ones
+    if (pl->lat[k].stride == 0 && pl->fused.state == 1) return pl->fused.stride;
     return pl->lat[k].stride;
 }
 
@@ -1348,6 +1679,43 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
     int max_users = 0;
     for (int v = 0; v < n_videos; ++v) max_users = videos[v].n_users > max_users ? videos[v].n_users : max_users;
     bool table = table_requested(pl, total, max_users);
+    if (table) {
+        // the plan's fused table: every video's frame blocks in one k_spatial_lut launch
+        int rc = ensure_fused(pl, s);
+        if (rc) return rc;
+        if (pl->fused.state == 1) {
+            const int N = pl->fused.lay.N;
+            const bool dedup = !getenv("VET_NO_DEDUP") && max_users >= env_int("VET_DEDUP_MIN_USERS", 1, 1 << 20, 128);
+            std::vector<vet::VideoDesc>& desc = c->batch_desc;
+            desc.resize(n_videos);
+            int block = 0;
+            size_t lds_max = 0;
+            bool fits = true;
+            for (int v = 0; v < n_videos && fits; ++v) {
+                const vet_video& x = videos[v];
+                vet::VideoDesc& d = desc[v];
+                d.mu = x.d_mu; d.mv = x.d_mv; d.U = x.n_users; d.T = x.n_frames;
+                d.entropy = x.d_entropy; d.assign = x.d_assign; d.present = x.d_present;
+                const size_t lds = batch_video_geometry(c, d.U, total_frames, N, dedup, &d.FPW, &d.UC);
+                if (lds == 0) fits = false;
+                d.block0 = block; d.pad_ = 0;
+                block += (d.T + d.FPW - 1) / d.FPW;
+                lds_max = lds > lds_max ? lds : lds_max;
+            }
+            if (fits) {
+                void* d_desc = nullptr;
+                rc = pooled(c, 7, desc.size() * sizeof(vet::VideoDesc), &d_desc);
+                if (rc) return rc;
+                HIP_TRY(hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(vet::VideoDesc), hipMemcpyHostToDevice, s));
+                const vet::SampleSrc src{nullptr, nullptr, nullptr, pl->W, pl->H, (long)pl->n_dirs};
+                bool launched = false;
+                rc = launch_lut_fused<false>(pl, src, 0, 0, (const vet::VideoDesc*)d_desc, n_videos, block, lds_max, max_users,
+                                             nullptr, nullptr, nullptr, nullptr, d_status, s, &launched);
+                if (launched) for (int k = 0; k < K; ++k) pl->lat[k].last_form = F_TABLE;
+                if (rc || launched) return rc;
+            }
+        }
+    }
     int form0 = F_SWEEP;
     for (int k = 0; k < K && table; ++k) {
         int form = F_SWEEP;

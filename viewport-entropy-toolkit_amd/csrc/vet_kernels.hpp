@@ -35,6 +35,7 @@
 #include "vet_spatial_sweep.hpp"
 #include "vet_weight_table.hpp"
 #include "vet_spatial_lut.hpp"
+#include "vet_spatial_rows.hpp"
 #include "vet_spatial_u.hpp"
 #include "vet_transition.hpp"
 #include "vet_geometry.hpp"

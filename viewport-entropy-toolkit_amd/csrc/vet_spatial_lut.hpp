@@ -14,6 +14,74 @@ namespace vet {
 // its UN rows only.
 // ------------------------------------------------------------------------------------------
 
+constexpr int MAX_LATTICES = 8;
+
+// ------------------------------------------------------------------------------------------
+// Fused histogram layout.  The plan's K lattices (analyzers/spatial_entropy.py:142-156 loops over
+// them per frame) share ONE histogram of N = Nr + 4K slots, Nr = 2 * (Hs + K), Hs = sum_k floor(n_k / 2):
+//     [ 2K total slots | first halves of lattices 0..K-1 | K centre slots | K mirrored centre slots |
+//       second halves, reversed | 2K mirrored total slots ]
+// laid out so that the ONE reflection pos -> N-1-pos maps every lattice onto itself the way the Fibonacci
+// lattice's mirror symmetry (x,y,z) -> (x,-y,-z) does (tile i <-> tile n_k-1-i, see ensure_alias): a direction
+// and its mirror image then share one fused table row, the mirrored one adding into N-1-pos.  The centre tile
+// of an odd lattice is its own mirror image; it owns two slots and the epilogue adds them.
+// Total slots: every table row ends with two pseudo entries per lattice — the high and low 32 bits of the sum
+// of the row's mantissas in that lattice — aimed at slots 2k / 2k+1, so the walk that builds the histogram also
+// builds its exact total (hi * 2^32 + lo) and the entropy pass needs no reduction of its own.
+// A distinct direction of a frame costs ONE row walk (one length word, one set-up) whatever K is, and the
+// short rows of small lattices share cache lines with the others (config 4, 51+101+201 tiles: 88 + 6 entries =
+// 5 lines instead of 3 rows x 3 lines + 2 meta words).
+// ------------------------------------------------------------------------------------------
+struct FusedLayout {
+    int K;
+    int n[MAX_LATTICES];        // tiles per lattice
+    int off[MAX_LATTICES];      // slot of tile 0 of lattice k = 2K + sum_{j<k} floor(n_j / 2)
+    int Hs, N;                  // N = 2 * (Hs + K) + 4K
+    int CF;                     // 64-tile chunks per frame = sum_k ceil(n_k / 64)
+    int totals;                 // the rows carry the pseudo entries of the total slots (else the epilogue sums the tiles)
+    double hmax[MAX_LATTICES];
+};
+__host__ __device__ __forceinline__ int fused_pos(const FusedLayout& L, int k, int i) {
+    const int h = L.n[k] >> 1;
+    if (i < h) return L.off[k] + i;
+    if (i >= L.n[k] - h) return L.N - 1 - (L.off[k] + (L.n[k] - 1 - i));
+    return 2 * L.K + L.Hs + k;
+}
+
+// wave-wide sums through DPP (row reductions + row broadcasts): the total in every lane, a fixed order
+#define VET_DPP(v, ctrl, rmask) __builtin_amdgcn_update_dpp(0, (v), (ctrl), (rmask), 0xF, true)
+__device__ __forceinline__ double wave_total(double v) {
+    auto step = [&](auto mov) {
+        const long long b = __double_as_longlong(v);
+        const int lo = mov((int)(b & 0xFFFFFFFFll)), hi = mov((int)(b >> 32));
+        return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+    };
+    v += step([](int x) { return VET_DPP(x, 0xB1, 0xF); });      // quad_perm [1,0,3,2]
+    v += step([](int x) { return VET_DPP(x, 0x4E, 0xF); });      // quad_perm [2,3,0,1]
+    v += step([](int x) { return VET_DPP(x, 0x141, 0xF); });     // row_half_mirror
+    v += step([](int x) { return VET_DPP(x, 0x140, 0xF); });     // row_mirror
+    v += step([](int x) { return VET_DPP(x, 0x142, 0xA); });     // row_bcast:15 into rows 1, 3
+    v += step([](int x) { return VET_DPP(x, 0x143, 0xC); });     // row_bcast:31 into rows 2, 3
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ unsigned long long wave_total(unsigned long long v) {
+    auto step = [&](auto mov) {
+        const int lo = mov((int)(v & 0xFFFFFFFFull)), hi = mov((int)(v >> 32));
+        return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+    };
+    v += step([](int x) { return VET_DPP(x, 0xB1, 0xF); });
+    v += step([](int x) { return VET_DPP(x, 0x4E, 0xF); });
+    v += step([](int x) { return VET_DPP(x, 0x141, 0xF); });
+    v += step([](int x) { return VET_DPP(x, 0x140, 0xF); });
+    v += step([](int x) { return VET_DPP(x, 0x142, 0xA); });
+    v += step([](int x) { return VET_DPP(x, 0x143, 0xC); });
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xFFFFFFFFull), 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 constexpr int ROW_BITS = 19;
 constexpr uint32_t ROW_MASK = (1u << ROW_BITS) - 1;
 
@@ -130,7 +198,6 @@ __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t*
 // entry * multiplicity into the frame histogram with ds_add_u64; a wave serves 64/GS rows at once and
 // two such steps are issued back to back to keep more loads in flight.
 // ------------------------------------------------------------------------------------------
-constexpr int MAX_LATTICES = 8;
 constexpr unsigned DEDUP_MAX_DIRS = (1u << 19) - 1;      // set key = row (19 bits) | mirror flag; slot = key << 12 | count
 
 struct LutLattice {
@@ -139,6 +206,7 @@ struct LutLattice {
     const uint32_t* tab_meta;
     int stride, gs_log2, n, interleaved;
     double hmax;
+    uint32_t zrow;                // index of the table's all-zero row (the number of its rows in use)
 };
 
 // One video of a batched launch (vet_spatial_entropy_batch): many short videos share one grid,
@@ -171,6 +239,8 @@ struct LutParams {
     int32_t* present;
     int32_t* status;
     int FPW, UC;
+    FusedLayout lay;              // FUSED: the launch's one "lattice" is the plan's fused table (n = lay.N slots)
+    unsigned long long* dbg;      // VET_LUT_DEBUG (FUSED): [4] cycles of thread 0 per stage, summed over the workgroups
     uint32_t* resolve;            // FP tables with marker entries: [0] = number of frames handed to the precise sweep
                                   // (a marked tile whose histogram stayed 0.0), then the frames; null otherwise
 };
@@ -198,7 +268,10 @@ __host__ __device__ __forceinline__ size_t lut_lds_bytes(int U, int UC, int FPW,
 // 2 % (random walk) to 6.5 % (clustered) faster on single-lattice plans and 7 % on batches of short
 // videos, but 2-4 % slower on one multi-lattice video (profiles/r01/v6_table_occupancy.log).
 // DEDUP: per-frame set of distinct rows with multiplicities (direction tables of < 2^20 rows).
-template <bool FROM_IDS, int UN, bool IL, bool OCC8, bool DEDUP, bool FPT>
+// FUSED: the table is the plan's fused one (FusedLayout above): one row per distinct direction over all lattices,
+// histogram slots instead of tiles, the exact total of every lattice in its total slots; the epilogue reads the
+// lattices back out of the fused histogram.
+template <bool FROM_IDS, int UN, bool IL, bool OCC8, bool DEDUP, bool FPT, bool FUSED = false>
 __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // the video this workgroup works on: the launch's only one, or one of a batch
@@ -237,6 +310,10 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const long f0 = blk * FPW;
     const int nf = (int)min((long)FPW, (long)T - f0);
+    unsigned long long tdbg[4] = {0, 0, 0, 0}, tlast = (FUSED && p.dbg) ? __builtin_readcyclecounter() : 0ull;
+    auto stage = [&](int i) {
+        if (FUSED && p.dbg) { const unsigned long long now = __builtin_readcyclecounter(); tdbg[i] += now - tlast; tlast = now; }
+    };
     if (!overlay)
         for (int i = tid; i < FPW * p.n_sum; i += blockDim.x) hist[i] = 0ull;
     for (int i = tid; i < 2 * FPW; i += blockDim.x) cnt_chunk[i] = 0;
@@ -364,6 +441,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
             }
         }
         __syncthreads();
+        stage(0);
         if (DEDUP) {
             // slot numbers -> slot words (row << 12 | multiplicity)
             for (int i = tid; i < nf * UC; i += blockDim.x) {
@@ -376,6 +454,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
             }
         }
         int hoff = 0;
+        stage(1);
         for (int k = 0; k < p.K; ++k) {
             const LutLattice& L = p.lat[k];
             // meta words (length, shift) of this lattice for every staged row: one parallel gather, so the
@@ -391,17 +470,69 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
                 if (IL && L.interleaved)
                     walk_rows<UN, true, DEDUP, FPT>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
                                                hist + (size_t)fl * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
-                                               (uint32_t)src.n_dirs * (uint32_t)L.stride, marked ? marked + (size_t)fl * MW : nullptr, hoff);
+                                               L.zrow * (uint32_t)L.stride, marked ? marked + (size_t)fl * MW : nullptr, hoff);
                 else
                     walk_rows<UN, false, DEDUP, FPT>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
                                                 hist + (size_t)fl * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
-                                                (uint32_t)src.n_dirs * (uint32_t)L.stride, marked ? marked + (size_t)fl * MW : nullptr, hoff);
+                                                L.zrow * (uint32_t)L.stride, marked ? marked + (size_t)fl * MW : nullptr, hoff);
             hoff += L.n;
         }
     }
     __syncthreads();
+    stage(2);
     // entropy (entropy_utils.py:194-211, weighted: normaliser log2 n); wave w takes frames w, w+NW, ...
     const double inv_unit = 1.0 / (4294967296.0 * (double)(1u << TAB_X));
+    if (FUSED) {
+        // exact total per lattice from the total slots; -sum p log2 p in a canonical order (64-tile chunks, a fixed
+        // reduction tree inside a chunk, chunks in order): bit-identical to k_spatial_rows on the same frame
+        const int N = p.lay.N, K = p.lay.K;
+        for (int fl = wv; fl < nf; fl += NW) {
+            const unsigned long long* hrow = hist + (size_t)fl * N;
+            double total_entropy = 0.0;
+            for (int k = 0; k < K; ++k) {
+                const int n = p.lay.n[k], hh = n >> 1;
+                unsigned long long hi = hrow[2 * k] + hrow[N - 1 - 2 * k], lo = hrow[2 * k + 1] + hrow[N - 2 - 2 * k];
+                if (!p.lay.totals) {
+                    hi = lo = 0ull;
+                    for (int t = lane; t < n; t += WAVE) {
+                        const int pos = fused_pos(p.lay, k, t);
+                        unsigned long long v = hrow[pos];
+                        if (t >= hh && t < n - hh) v += hrow[N - 1 - pos];
+                        hi += v >> 32; lo += v & 0xFFFFFFFFull;
+                    }
+                    hi = wave_total(hi); lo = wave_total(lo);
+                }
+                const double totd = (double)(hi + (lo >> 32)) * 4294967296.0 + (double)(lo & 0xFFFFFFFFull);
+                double hk = 0.0;
+                for (int t0 = 0; t0 < n; t0 += WAVE) {
+                    const int t = t0 + lane;
+                    double term = 0.0;
+                    if (t < n) {
+                        const int pos = fused_pos(p.lay, k, t);
+                        unsigned long long v = hrow[pos];
+                        if (t >= hh && t < n - hh) v += hrow[N - 1 - pos];          // centre tile: both of its slots
+                        if (v != 0ull) {
+                            const double qv = (double)v / totd;
+                            term = -(qv * log2(qv));
+                        }
+                        if (k == 0 && weights) __builtin_nontemporal_store((double)v * inv_unit, weights + (f0 + fl) * (long)n + t);
+                    }
+                    hk += wave_total(term);
+                }
+                total_entropy += hk / p.lay.hmax[k];
+            }
+            if (lane == 0) {
+                const int np = cnt_frame[fl];
+                double e = total_entropy / (double)K;
+                if (np == 0) {
+                    e = __builtin_nan("");
+                    if (p.status) atomicAdd(&p.status[1], 1);
+                }
+                entropy[f0 + fl] = e;
+                if (present) present[f0 + fl] = np;
+            }
+        }
+    } else
     for (int fl = wv; fl < nf; fl += NW) {
         const unsigned long long* hrow = hist + (size_t)fl * p.n_sum;
         double total_entropy = 0.0;
@@ -443,6 +574,11 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
             entropy[f0 + fl] = e;
             if (present) present[f0 + fl] = np;
         }
+    }
+    if (FUSED && p.dbg) {
+        stage(3);
+        if (tid == 0)
+            for (int i = 0; i < 4; ++i) atomicAdd(&p.dbg[i], tdbg[i]);
     }
     if (p.status) {
         const unsigned long long anybad = __ballot(bad);

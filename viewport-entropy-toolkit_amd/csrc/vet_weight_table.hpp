@@ -57,6 +57,10 @@ struct StatsParams {
                                 //   [0] max_d 36.5 q_d k_d / (S_d H_d)   with the table's q_d = 2^(e_d - 33)
                                 //   [1] max_d 36.5 k_d / (S_d H_d)       (times the sweep's step, 2^(shift-53))
                                 //   [2] number of in-FoV (direction, tile) pairs with an ultra-tiny weight (atomicAdd)
+    // fused-table pass: rows r -> direction canon[r], the block-floating-point shift is the ROW's shared one
+    // (shift_in[r], k_fuse_shifts) instead of the lattice's own; only crit[0] is produced
+    const int* canon;
+    const uint8_t* shift_in;
 };
 
 __device__ __forceinline__ double wave_max(double v) {
@@ -71,7 +75,8 @@ __global__ void k_row_stats(const StatsParams p) {
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
     double worst_tab = 0.0, worst_sweep = 0.0;
     int ultra = 0;
-    for (long d = wave; d < p.D; d += nwaves) {
+    for (long r = wave; r < p.D; r += nwaves) {
+        const long d = p.canon ? (long)p.canon[r] : r;
         const double dx = p.dir_unit[3 * d], dy = p.dir_unit[3 * d + 1], dz = p.dir_unit[3 * d + 2];
         double S = 0.0, L = 0.0, mx = 0.0;
         int k = 0;
@@ -89,9 +94,10 @@ __global__ void k_row_stats(const StatsParams p) {
         k = wave_sum(k); S = wave_sum(S); L = wave_sum(L); mx = wave_max(mx);
         int e = 0;
         if (mx > 0.0) (void)frexp(mx, &e);                  // mx <= 2^e
-        if (lane == 0) p.row_e[d] = (uint16_t)min(1000, max(0, -e));      // 2^E stays finite; weights below 2^-1048 are markers
+        if (lane == 0 && !p.canon) p.row_e[d] = (uint16_t)min(1000, max(0, -e));      // 2^E stays finite; weights below 2^-1048 are markers
         e = min(0, max(-TAB_X, e));
-        if (lane == 0) p.row_s[d] = (uint8_t)(TAB_X + e);
+        if (lane == 0 && !p.canon) p.row_s[d] = (uint8_t)(TAB_X + e);
+        if (p.canon) e = (int)p.shift_in[r] - TAB_X;
         if (k >= 1) {
             // row entropy -sum (w/S) log2(w/S) = log2 S - (sum w log2 w) / S; its own rounding error (~1e-15)
             // only matters where the bound is hopeless anyway
@@ -104,7 +110,7 @@ __global__ void k_row_stats(const StatsParams p) {
     ultra = wave_sum(ultra);
     if (lane == 0) {
         if (ultra) atomicAdd(&p.crit[2], (unsigned long long)ultra);
-        if (p.row_s && wave == 0) { p.row_s[p.D] = (uint8_t)TAB_X; p.row_e[p.D] = 0; }
+        if (p.row_s && !p.canon && wave == 0) { p.row_s[p.D] = (uint8_t)TAB_X; p.row_e[p.D] = 0; }
         if (worst_tab > 0.0) atomicMax(&p.crit[0], (unsigned long long)__double_as_longlong(worst_tab));
         if (worst_sweep > 0.0) atomicMax(&p.crit[1], (unsigned long long)__double_as_longlong(worst_sweep));
     }
@@ -125,6 +131,15 @@ struct WtabParams {
     const uint16_t* row_e;
     int fp;             // FP table: entries are FP32 weights scaled by 2^E of their row, meta field = E
     int* markers;       // FP table fill: number of marker entries written (in-FoV tiles without an FP32 value)
+    // fused table (vet_spatial_rows.hpp): row r belongs to direction canon[r] and runs over the nl lattices of the plan,
+    // an entry's tile index is its slot in the fused histogram; lens[r] = entries | shift << 11.  canon == null: the
+    // single-lattice table above (row = direction, slot = tile).
+    const int* canon;
+    int nl;
+    const double* tiles_v[8];
+    int n_v[8], off_v[8];
+    int Hs, N, totals;
+    uint16_t* lens;
     int* maxcount;
     int gs_log2;        // >= 0: well-filled blocks dealt over the 2^gs_log2 lanes of a gather group
 };
@@ -158,16 +173,24 @@ __global__ void k_wtab(const WtabParams p) {
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
     int longest = 0, nmark = 0;
+    const int nl = p.canon ? p.nl : 1;
+    const int slots = p.canon ? p.N : p.n;                  // histogram slots the padding cycles through
     for (long d = wave; d < p.D; d += nwaves) {
-        const double dx = p.dir_unit[3 * d], dy = p.dir_unit[3 * d + 1], dz = p.dir_unit[3 * d + 2];
+        const long dd = p.canon ? (long)p.canon[d] : d;     // the row's direction
+        const double dx = p.dir_unit[3 * dd], dy = p.dir_unit[3 * dd + 1], dz = p.dir_unit[3 * dd + 2];
         int count = 0;
         const int row_shift = FILL ? (p.fp ? (int)p.row_e[d] : (int)p.row_s[d]) : 0;
         const double scale = p.fp ? ldexp(1.0, row_shift) : ldexp(1.0, 32 + TAB_X - row_shift);        // 2^E / 2^(32 - e)
-        for (int t0 = 0; t0 < p.n; t0 += WAVE) {
+        unsigned long long rsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // fused rows: sum of the row's mantissas per lattice
+        for (int l = 0; l < nl; ++l) {
+        const double* tiles = p.canon ? p.tiles_v[l] : p.tiles;
+        const int n = p.canon ? p.n_v[l] : p.n;
+        unsigned long long lsum = 0ull;
+        for (int t0 = 0; t0 < n; t0 += WAVE) {
             const int t = t0 + lane;
-            const bool valid = t < p.n;
+            const bool valid = t < n;
             const int ts = valid ? t : 0;
-            const double c = fma(dz, p.tiles[3 * ts + 2], fma(dy, p.tiles[3 * ts + 1], dx * p.tiles[3 * ts]));
+            const double c = fma(dz, tiles[3 * ts + 2], fma(dy, tiles[3 * ts + 1], dx * tiles[3 * ts]));
             bool hit = valid && (c > p.cos_cull);
             unsigned w32 = 0u;
             if (FILL) {
@@ -185,11 +208,33 @@ __global__ void k_wtab(const WtabParams p) {
                 hit = w32 != 0u;
             }
             const unsigned long long mask = __ballot(hit);
+            if (FILL && hit) lsum += w32;
             if (FILL && hit) {
                 const int pos = count + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                int slot = t;
+                if (p.canon) {                                  // fused_pos
+                    const int h = n >> 1;
+                    slot = t < h ? p.off_v[l] + t : (t >= n - h ? p.N - 1 - (p.off_v[l] + (n - 1 - t)) : 2 * p.nl + p.Hs + l);
+                }
                 p.w[d * p.stride + pos] = w32;
-                p.idx[d * p.stride + pos] = (uint16_t)t;
+                p.idx[d * p.stride + pos] = (uint16_t)slot;
+            }
+            count += __popcll(mask);
+        }
+        if (p.canon && FILL) rsum[l] = wave_sum(lsum);
+        }
+        if (p.canon && p.totals) {
+            // two pseudo entries per lattice: high / low 32 bits of the lattice's mantissa sum -> total slots 2l, 2l+1
+            // (vet_spatial_rows.hpp); a zero half is left out like any zero entry.  The count pass reserves all of them.
+            unsigned w32 = 0u;
+            if (FILL && lane < 2 * nl) w32 = (lane & 1) ? (unsigned)(rsum[lane >> 1] & 0xFFFFFFFFull) : (unsigned)(rsum[lane >> 1] >> 32);
+            const bool hit = FILL ? w32 != 0u : lane < 2 * nl;
+            const unsigned long long mask = __ballot(hit);
+            if (FILL && hit) {
+                const int pos = count + below(mask);
+                p.w[d * p.stride + pos] = w32;
+                p.idx[d * p.stride + pos] = (uint16_t)lane;
             }
             count += __popcll(mask);
         }
@@ -198,9 +243,12 @@ __global__ void k_wtab(const WtabParams p) {
             // without piling zero adds onto one LDS address
             for (int pos = count + lane; pos < p.stride; pos += WAVE) {
                 p.w[d * p.stride + pos] = 0u;
-                p.idx[d * p.stride + pos] = (uint16_t)(pos % p.n);
+                p.idx[d * p.stride + pos] = (uint16_t)(pos % slots);
             }
-            if (lane == 0) p.meta[d] = (uint32_t)count | ((uint32_t)row_shift << 16);
+            if (lane == 0) {
+                if (p.meta) p.meta[d] = (uint32_t)count | ((uint32_t)row_shift << 16);
+                if (p.lens) p.lens[d] = (uint16_t)(count | (row_shift << 11));
+            }
             // well-filled blocks of 16-lane rows: deal the entries by class (one wave pass per block, lane =
             // sorted entry; the loads of all lanes have returned before the first store issues)
             if (p.gs_log2 == 4) {
@@ -264,12 +312,38 @@ __global__ void k_wtab(const WtabParams p) {
         for (int pos = lane; pos < p.stride; pos += WAVE) {
             p.w[p.D * p.stride + pos] = 0u;
             // lane l of a 16-lane group adds its zeros to tile l: 16 classes, no conflict
-            p.idx[p.D * p.stride + pos] = (uint16_t)(p.gs_log2 == 4 ? (pos >> 2) & 15 : pos % p.n);
+            p.idx[p.D * p.stride + pos] = (uint16_t)(p.gs_log2 == 4 ? (pos >> 2) & 15 : pos % slots);
         }
-        if (lane == 0) p.meta[p.D] = p.fp ? 0u : (uint32_t)TAB_X << 16;
+        if (lane == 0) {
+            if (p.meta) p.meta[p.D] = p.fp ? 0u : (uint32_t)TAB_X << 16;
+            if (p.lens) { p.lens[p.D] = (uint16_t)(TAB_X << 11); p.lens[p.D + 1] = 0; }
+        }
     }
 }
 
+
+// Fused rows: one block-floating-point shift per row = the coarsest of the lattices' own shifts (k_row_stats);
+// delta[k] = the most any row of lattice k loses against its own shift (the lattice's error bound grows by 2^delta)
+__global__ void k_fuse_shifts(const int* __restrict__ canon, int R, int nl, const uint8_t* const* __restrict__ row_s,
+                              uint8_t* __restrict__ out, int* __restrict__ delta) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+        const int d = canon[r];
+        int s = 0;
+        for (int k = 0; k < nl; ++k) s = max(s, (int)row_s[k][d]);
+        out[r] = (uint8_t)s;
+        for (int k = 0; k < nl; ++k)
+            if (s > (int)row_s[k][d]) atomicMax(&delta[k], s - (int)row_s[k][d]);
+    }
+}
+
+// Per-direction record of k_spatial_rows (copied to LDS): fused row (15 bits) | mirrored << 15 | nearest tile << 16
+__global__ void k_rowrec(const uint32_t* __restrict__ rowsel, const uint16_t* __restrict__ nearest, long D,
+                         uint32_t* __restrict__ rec) {
+    for (long d = blockIdx.x * (long)blockDim.x + threadIdx.x; d < D; d += (long)gridDim.x * blockDim.x) {
+        const uint32_t a = rowsel[d];
+        rec[d] = (a & 0x7FFFu) | ((a >> 31) << 15) | ((uint32_t)nearest[d] << 16);
+    }
+}
 
 // Per-direction record of the table kernel's prologue: one 8-byte gather per sample instead of three
 // (alias, nearest tile, row meta):  x = row (19 bits) | nearest tile bits 0..11 << 19 | mirrored << 31
