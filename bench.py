@@ -39,11 +39,15 @@ WORKLOADS = {
     "config5": (512, 10000, [200], "transition", True),
     # 64 config-2-sized videos per GPU in one launch (vet_spatial_entropy_batch); --loop runs them one by one
     "config2x64": (64, 3000, [50, 100, 200], "spatial", True),
+    "config2x64u": (64, 3000, [50, 100, 200], "spatial", False),      # the same batch, nearest-tile counts (k_spatial_u_lds)
+    "config2x64t": (64, 3000, [50, 100, 200], "transition", True),    # the same batch in transition mode (k_transition_run)
+    # 64 videos of config 5's audience (512 users, tile_counts=[200]) x 1000 frames, transition mode, one launch
+    "config5x64": (512, 1000, [200], "transition", True),
     # the reference's default AnalyzerConfig.tile_counts (config.py:27) on a config-4-sized video
     "defaults": (256, 10000, [20, 50, 100, 250, 1000], "spatial", True),
     "defaults_u": (256, 10000, [20, 50, 100, 250, 1000], "spatial", False),
 }
-BATCH = {"config2x64": 64}
+BATCH = {"config2x64": 64, "config2x64u": 64, "config2x64t": 64, "config5x64": 64}
 
 
 def synth_video(U, T, seed, video_id, kind="random_walk"):
@@ -234,8 +238,8 @@ def main():
         import ctypes as C
         mus = [torch.from_numpy(synth_video(U, T, args.seed, rank * n_batch + v, args.data)[0]).to(dev) for v in range(n_batch)]
         mvs = [torch.from_numpy(synth_video(U, T, args.seed, rank * n_batch + v, args.data)[1]).to(dev) for v in range(n_batch)]
-        ents = [torch.empty(T, dtype=torch.float64, device=dev) for _ in range(n_batch)]
-        idxs = [torch.empty((T, U), dtype=torch.int32, device=dev) for _ in range(n_batch)]
+        ents = [torch.empty(R, dtype=torch.float64, device=dev) for _ in range(n_batch)]
+        idxs = [torch.empty((T, U) if mode == "spatial" else (R, U, 2), dtype=torch.int32, device=dev) for _ in range(n_batch)]
         vids = (_native.Video * n_batch)(*[_native.Video(mus[v].data_ptr(), mvs[v].data_ptr(), U, T, ents[v].data_ptr(),
                                                          idxs[v].data_ptr(), None) for v in range(n_batch)])
 
@@ -249,10 +253,16 @@ def main():
         if n_batch > 1:
             if args.loop:
                 for v in range(n_batch):
-                    plan.spatial_device(mus[v].data_ptr(), mvs[v].data_ptr(), U, T, ents[v].data_ptr(),
-                                        d_assign=idxs[v].data_ptr(), d_status=status.data_ptr(), stream=stream)
-            else:
+                    if mode == "spatial":
+                        plan.spatial_device(mus[v].data_ptr(), mvs[v].data_ptr(), U, T, ents[v].data_ptr(),
+                                            d_assign=idxs[v].data_ptr(), d_status=status.data_ptr(), stream=stream)
+                    else:
+                        plan.transition_device(mus[v].data_ptr(), mvs[v].data_ptr(), U, T, ents[v].data_ptr(),
+                                               d_pairs=idxs[v].data_ptr(), d_status=status.data_ptr(), stream=stream)
+            elif mode == "spatial":
                 plan.spatial_batch_device(vids, d_status=status.data_ptr(), stream=stream)
+            else:
+                plan.transition_batch_device(vids, d_status=status.data_ptr(), stream=stream)
             if multi:
                 dist.gather(ents[0], gathered, dst=0)
             return

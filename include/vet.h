@@ -191,9 +191,12 @@ int vet_transition_entropy_ids(vet_plan *plan, const int32_t *d_ids, int n_users
                                int32_t *d_common, int32_t *d_status, void *stream);
 
 /* ---- many videos, one launch ---------------------------------------------------
- * Short videos are launch-bound one call at a time; a batch shares one grid (weighted table
- * formulation; other modes run video by video inside the call).  Lattice 0's tile weights are not
- * produced by the batched form.  Asynchronous on ``stream`` like vet_spatial_entropy. */
+ * Short videos are launch-bound one call at a time (the reference's scale-out unit is "many short videos",
+ * README.md:108-120); a batch shares one grid: the weighted table formulation (k_spatial_lut over the plan's fused
+ * table), the nearest-tile / binned modes (k_spatial_u_lds, one launch per lattice) and transition mode
+ * (k_transition_run, one launch per lattice, every video with its own workgroups).  Batches outside those kernels'
+ * limits run video by video inside the call.  Lattice 0's tile weights / source counts are not produced by the
+ * batched forms.  Asynchronous on ``stream`` like vet_spatial_entropy. */
 typedef struct vet_video {
     const double *d_mu, *d_mv;   /* [n_frames * n_users], frame-major */
     int n_users, n_frames;
@@ -207,6 +210,14 @@ int vet_spatial_entropy_batch(vet_plan *plan, int n_videos, const vet_video *vid
 int vet_spatial_entropy_batch_host(vet_plan *plan, int n_videos, const int *n_users, const int *n_frames,
                                    const double *h_mu, const double *h_mv, double *h_entropy,
                                    int32_t *h_assign, int32_t *h_present);
+/* Transition mode (TransitionEntropyAnalyzer.compute_entropy per video, analyzers/transition_entropy.py:107-175):
+ * d_entropy [n_frames-1], d_assign = the (prior, current) tile pairs [(n_frames-1) * n_users * 2] or NULL,
+ * d_present = users present in both frames [n_frames-1] or NULL; every video needs at least two frames. */
+int vet_transition_entropy_batch(vet_plan *plan, int n_videos, const vet_video *videos, int32_t *d_status,
+                                 void *stream);
+int vet_transition_entropy_batch_host(vet_plan *plan, int n_videos, const int *n_users, const int *n_frames,
+                                      const double *h_mu, const double *h_mv, double *h_entropy,
+                                      int32_t *h_pairs, int32_t *h_common);
 
 /* ---- host-buffer convenience: H2D, run, D2H, synchronous ------------------
  * Return VET_ERR_RANGE / VET_ERR_EMPTY when the status words are non-zero (outputs are still

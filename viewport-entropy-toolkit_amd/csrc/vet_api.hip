@@ -1103,8 +1103,12 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
             const bool pairs = (U & 1) == 0;
             int FB = 4096 / U;
             if (FB > 64) FB = 64;
-            const size_t lds = (((size_t)pl->n_dirs * 2 + 15) & ~(size_t)15) + (size_t)(U + 1) * 8 +
-                               ((((size_t)FB * L.n + 1) & ~(size_t)1) * 4) + (size_t)FB * (THREADS / 64) * 8 + FB * 4 + 16;
+            auto lds_of = [&](int fb) {
+                return (((size_t)pl->n_dirs * 2 + 15) & ~(size_t)15) + (size_t)(U + 1) * 8 +
+                       ((((size_t)fb * L.n + 1) & ~(size_t)1) * 4) + (size_t)fb * (THREADS / 64) * 8 + fb * 4 + 16;
+            };
+            while (FB > 1 && lds_of(FB) > c->lds_max) FB /= 2;      // few users x many tiles: fewer frames per round
+            const size_t lds = lds_of(FB);
             if (lds <= c->lds_max) {
                 vet::SpatialParams q = p;
                 q.FPW = FB;
@@ -1661,6 +1665,111 @@ int vet_transition_entropy_ids(vet_plan* pl, const int32_t* d_ids, int U, int T,
 // one call per video when the table formulation does not apply.
 static int pooled(vet_ctx* c, int slot, size_t bytes, void** out);
 
+// Unweighted (nearest-tile) batch: every video's frame blocks in ONE k_spatial_u_lds launch per lattice; with several
+// lattices the per-lattice values go through the workspace and k_finalize_batch forms the means.  Returns launched =
+// false when the batch does not fit the kernel (odd shapes, LUT too large for LDS): the caller loops over the videos.
+static int batch_unweighted(vet_plan* pl, int n_videos, const vet_video* videos, int32_t* d_status, hipStream_t s, bool* launched) {
+    *launched = false;
+    vet_ctx* c = pl->ctx;
+    const int K = (int)pl->lat.size();
+    if (getenv("VET_U_NO_LDS")) return VET_OK;
+    int max_users = 0;
+    bool pairs = true;
+    long frames = 0;
+    for (int v = 0; v < n_videos; ++v) {
+        max_users = std::max(max_users, videos[v].n_users);
+        pairs = pairs && (videos[v].n_users & 1) == 0;
+        frames += videos[v].n_frames;
+    }
+    if (max_users > 4096) return VET_OK;
+    constexpr int THREADS = 1024;
+    std::vector<vet::VideoDesc> desc((size_t)n_videos * K);
+    std::vector<long> frame0((size_t)n_videos + 1);
+    std::vector<double*> outs(n_videos);
+    int n_max = 0;
+    for (const auto& L : pl->lat) n_max = std::max(n_max, L.n);
+    auto lds_of = [&](int fb) {
+        return (((size_t)pl->n_dirs * 2 + 15) & ~(size_t)15) + (size_t)(max_users + 1) * 8 +
+               ((((size_t)fb * n_max + 1) & ~(size_t)1) * 4) + (size_t)fb * (THREADS / 64) * 8 + fb * 4 + 16;
+    };
+    int fb_cap = 64;
+    while (fb_cap > 1 && lds_of(fb_cap) > c->lds_max) fb_cap /= 2;
+    int fb_max = 1, block = 0;
+    for (int v = 0; v < n_videos; ++v) {
+        const vet_video& x = videos[v];
+        int fb = 4096 / x.n_users;
+        if (fb > fb_cap) fb = fb_cap;
+        if (fb < 1) fb = 1;
+        fb_max = std::max(fb_max, fb);
+        frame0[v] = v ? frame0[v - 1] + videos[v - 1].n_frames : 0;
+        outs[v] = x.d_entropy;
+        vet::VideoDesc& d = desc[v];
+        d.mu = x.d_mu; d.mv = x.d_mv; d.U = x.n_users; d.T = x.n_frames;
+        d.entropy = x.d_entropy; d.assign = x.d_assign; d.present = x.d_present;
+        d.FPW = fb; d.UC = 0; d.block0 = block; d.pad_ = 0;
+        block += (x.n_frames + fb - 1) / fb;
+    }
+    frame0[n_videos] = frames;
+    const size_t lds = lds_of(fb_max);
+    if (lds > c->lds_max) return VET_OK;
+    double* ws = nullptr;
+    if (K > 1) {
+        int rc = ensure_ws(c, (size_t)K * frames * sizeof(double));
+        if (rc) return rc;
+        ws = (double*)c->ws;
+        for (int k = 0; k < K; ++k)
+            for (int v = 0; v < n_videos; ++v) {
+                vet::VideoDesc& d = desc[(size_t)k * n_videos + v];
+                d = desc[v];
+                d.entropy = ws + (size_t)k * frames + frame0[v];
+                if (k) { d.assign = nullptr; d.present = nullptr; }
+            }
+        // (desc[v] of lattice 0 was overwritten last: its entropy now points into the workspace too)
+    }
+    void* d_desc = nullptr;
+    int rc = pooled(c, 7, desc.size() * sizeof(vet::VideoDesc) + (frame0.size() + outs.size()) * 8, &d_desc);
+    if (rc) return rc;
+    char* base = (char*)d_desc;
+    long* d_frame0 = (long*)(base + desc.size() * sizeof(vet::VideoDesc));
+    double** d_outs = (double**)(d_frame0 + frame0.size());
+    c->batch_desc = desc;                          // host copies stay alive until the copies below have run
+    HIP_TRY(hipMemcpyAsync(base, c->batch_desc.data(), desc.size() * sizeof(vet::VideoDesc), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_frame0, frame0.data(), frame0.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_outs, outs.data(), outs.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));              // frame0 / outs are locals (pageable copies are staged, this is belt and braces)
+    for (int k = 0; k < K; ++k) {
+        const Lattice& L = pl->lat[k];
+        vet::SpatialParams q{};
+        q.src = vet::SampleSrc{nullptr, nullptr, nullptr, pl->W, pl->H, (long)pl->n_dirs};
+        q.U = max_users; q.T = 0;
+        q.nearest = L.d_nearest; q.n = L.n; q.hmax = L.hmax;
+        q.status = k == 0 ? d_status : nullptr;
+        q.FPW = fb_max;
+        q.log2_tab = c->d_log2;
+        q.full_norm = (L.binned && pl->weighted) ? 1 : 0;
+        q.norm_n = L.norm_n;
+        q.videos = (const vet::VideoDesc*)base + (size_t)k * n_videos;
+        q.n_videos = n_videos; q.n_blocks = block;
+        long grid = (long)c->n_cu * env_int("VET_U_WGS_PER_CU", 1, 8, 2);
+        if (grid > block) grid = block;
+        const long rounds = (block + grid - 1) / grid;
+        grid = (block + rounds - 1) / rounds;
+        ProfScope ps(c, s, KID_SPATIAL);
+        const void* fn = pairs ? (const void*)vet::k_spatial_u_lds<false, true> : (const void*)vet::k_spatial_u_lds<false, false>;
+        void* args[] = {(void*)&q};
+        HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(THREADS), args, lds, s));
+        HIP_TRY(hipGetLastError());
+    }
+    if (K > 1) {
+        ProfScope ps(c, s, KID_FINALIZE);
+        hipLaunchKernelGGL(vet::k_finalize_batch, dim3(grid_for(frames, 256, c->n_cu)), dim3(256), 0, s, (const double*)ws, K, frames,
+                           (const long*)d_frame0, (double* const*)d_outs, n_videos);
+        HIP_TRY(hipGetLastError());
+    }
+    *launched = true;
+    return VET_OK;
+}
+
 int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* videos, int32_t* d_status, void* stream) {
     if (!pl) return fail(VET_ERR_INVALID, "plan is NULL");
     if (n_videos <= 0 || !videos) return fail(VET_ERR_INVALID, "need at least one video");
@@ -1678,6 +1787,16 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
     }
     int max_users = 0;
     for (int v = 0; v < n_videos; ++v) max_users = videos[v].n_users > max_users ? videos[v].n_users : max_users;
+    if (!pl->weighted || any_binned(pl)) {
+        // nearest-tile counts (unweighted mode, binned lattices): one k_spatial_u_lds launch per lattice for all videos
+        bool all_counts = true;
+        for (const auto& L : pl->lat) all_counts = all_counts && (!pl->weighted || L.binned);
+        if (all_counts) {
+            bool launched = false;
+            int rc = batch_unweighted(pl, n_videos, videos, d_status, s, &launched);
+            if (rc || launched) return rc;
+        }
+    }
     bool table = table_requested(pl, total, max_users);
     if (table) {
         // the plan's fused table: every video's frame blocks in one k_spatial_lut launch
@@ -1764,6 +1883,125 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
         int rc = vet_spatial_entropy(pl, x.d_mu, x.d_mv, x.n_users, x.n_frames, x.d_entropy, x.d_assign, nullptr,
                                      x.d_present, d_status, s);
         if (rc) return rc;
+    }
+    return VET_OK;
+}
+
+// Transition mode over a batch of videos: ONE k_transition_run launch per lattice, every video with its own
+// workgroups (in proportion to its rows).  d_entropy [T-1], d_assign = pairs [(T-1)*U*2] (nullable), d_present =
+// users present in both frames [T-1] (nullable).  Batches that do not fit the LDS kernel run video by video.
+int vet_transition_entropy_batch(vet_plan* pl, int n_videos, const vet_video* videos, int32_t* d_status, void* stream) {
+    if (!pl) return fail(VET_ERR_INVALID, "plan is NULL");
+    if (n_videos <= 0 || !videos) return fail(VET_ERR_INVALID, "need at least one video");
+    if (!pl->grid) return fail(VET_ERR_INVALID, "plan has no pixel grid");
+    vet_ctx* c = pl->ctx;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const int K = (int)pl->lat.size();
+    int max_users = 0, min_users = 1 << 30;
+    long rows = 0;
+    for (int v = 0; v < n_videos; ++v) {
+        const vet_video& x = videos[v];
+        if (x.n_users <= 0 || x.n_frames <= 0 || !x.d_mu || !x.d_mv || !x.d_entropy)
+            return fail(VET_ERR_INVALID, "video %d: bad shape or NULL pointer", v);
+        max_users = std::max(max_users, x.n_users);
+        min_users = std::min(min_users, x.n_users);
+        rows += x.n_frames > 1 ? x.n_frames - 1 : 0;
+    }
+    int HS = 64, lg = 6;
+    while (HS < 2 * max_users) { HS <<= 1; ++lg; }
+    size_t n4_max = 0;
+    for (const auto& L : pl->lat) n4_max = std::max(n4_max, ((size_t)L.n + 3) & ~(size_t)3);
+    const size_t lds_cap = 160 * 1024 - 512;
+    const size_t lds_run = 2 * 20 * 8 + 4 * n4_max * 4 + (size_t)3 * HS * 4 + ((size_t)max_users + 2) * 8;
+    bool one_launch = rows > 0 && max_users <= 4096 && lds_run <= lds_cap && !getenv("VET_T_GLOBAL");
+    for (int v = 0; v < n_videos; ++v) one_launch = one_launch && videos[v].n_frames > 1;
+    if (!one_launch) {
+        for (int v = 0; v < n_videos; ++v) {
+            const vet_video& x = videos[v];
+            int rc = vet_transition_entropy(pl, x.d_mu, x.d_mv, x.n_users, x.n_frames, x.d_entropy, x.d_assign, nullptr,
+                                            x.d_present, d_status, s);
+            if (rc) return rc;
+        }
+        return VET_OK;
+    }
+    int threads = max_users <= 512 ? 128 : (max_users <= 2048 ? 512 : 1024);
+    threads = env_threads("VET_T_THREADS", threads);
+    int upt = (max_users + threads - 1) / threads;
+    upt = upt <= 1 ? 1 : (upt <= 2 ? 2 : (upt <= 4 ? 4 : 8));
+    while ((long)upt * threads < max_users) threads *= 2;
+    long per_cu = (long)(lds_cap / lds_run);
+    const long by_waves = 32 / (threads / 64);
+    if (per_cu > by_waves) per_cu = by_waves;
+    per_cu = env_int("VET_T_WGS_PER_CU", 1, 16, (int)(per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu)));
+    long grid_want = (long)c->n_cu * per_cu;
+    if (grid_want > rows) grid_want = rows;
+    if (grid_want < n_videos) grid_want = n_videos;
+    std::vector<vet::TransVideo> tv((size_t)n_videos * K);
+    std::vector<long> row0((size_t)n_videos + 1);
+    std::vector<double*> outs(n_videos);
+    int wg = 0;
+    for (int v = 0; v < n_videos; ++v) {
+        const vet_video& x = videos[v];
+        const long R = x.n_frames - 1;
+        long n_wgs = (grid_want * R + rows / 2) / rows;
+        if (n_wgs < 1) n_wgs = 1;
+        if (n_wgs > R) n_wgs = R;
+        row0[v] = v ? row0[v - 1] + (videos[v - 1].n_frames - 1) : 0;
+        outs[v] = x.d_entropy;
+        vet::TransVideo& d = tv[v];
+        d.mu = x.d_mu; d.mv = x.d_mv; d.U = x.n_users; d.T = x.n_frames;
+        d.ent = x.d_entropy; d.pairs = x.d_assign; d.common = x.d_present;
+        d.wg0 = wg; d.n_wgs = (int)n_wgs; d.run_q = (int)(R / n_wgs); d.run_r = (int)(R % n_wgs);
+        wg += (int)n_wgs;
+    }
+    row0[n_videos] = rows;
+    double* ws = nullptr;
+    if (K > 1) {
+        int rc = ensure_ws(c, (size_t)K * rows * sizeof(double));
+        if (rc) return rc;
+        ws = (double*)c->ws;
+        for (int k = K - 1; k >= 0; --k)
+            for (int v = 0; v < n_videos; ++v) {
+                vet::TransVideo& d = tv[(size_t)k * n_videos + v];
+                d = tv[v];
+                d.ent = ws + (size_t)k * rows + row0[v];
+                if (k) { d.pairs = nullptr; d.common = nullptr; }
+            }
+    }
+    void* d_buf = nullptr;
+    int rc = pooled(c, 7, tv.size() * sizeof(vet::TransVideo) + (row0.size() + outs.size()) * 8, &d_buf);
+    if (rc) return rc;
+    char* base = (char*)d_buf;
+    long* d_row0 = (long*)(base + tv.size() * sizeof(vet::TransVideo));
+    double** d_outs = (double**)(d_row0 + row0.size());
+    HIP_TRY(hipMemcpyAsync(base, tv.data(), tv.size() * sizeof(vet::TransVideo), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_row0, row0.data(), row0.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_outs, outs.data(), outs.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));              // the descriptors are locals
+    const bool exact = min_users == max_users && (long)upt * threads == max_users;
+    for (int k = 0; k < K; ++k) {
+        const Lattice& L = pl->lat[k];
+        vet::TransParams p{};
+        p.src = vet::SampleSrc{nullptr, nullptr, nullptr, pl->W, pl->H, (long)pl->n_dirs};
+        p.U = max_users; p.T = 0;
+        p.nearest = L.d_nearest; p.n = L.n; p.hmax = L.hmax;
+        p.status = k == 0 ? d_status : nullptr;
+        p.HS = HS; p.hs_shift = 32 - lg;
+        p.log2_tab = c->d_log2;
+        p.videos = (const vet::TransVideo*)base + (size_t)k * n_videos; p.n_videos = n_videos;
+        const size_t n4 = ((size_t)L.n + 3) & ~(size_t)3;
+        const size_t lds = 2 * 20 * 8 + 4 * n4 * 4 + (size_t)3 * HS * 4 + ((size_t)max_users + 2) * 8;
+        ProfScope ps(c, s, KID_TRANSITION);
+        const void* fn = transition_run_kernel<false>(upt, exact, threads);
+        void* args[] = {(void*)&p};
+        HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)wg), dim3(threads), args, lds, s));
+        HIP_TRY(hipGetLastError());
+    }
+    if (K > 1) {
+        ProfScope ps(c, s, KID_FINALIZE);
+        hipLaunchKernelGGL(vet::k_finalize_batch, dim3(grid_for(rows, 256, c->n_cu)), dim3(256), 0, s, (const double*)ws, K, rows,
+                           (const long*)d_row0, (double* const*)d_outs, n_videos);
+        HIP_TRY(hipGetLastError());
     }
     return VET_OK;
 }
@@ -1962,6 +2200,56 @@ int vet_spatial_entropy_batch_host(vet_plan* pl, int n_videos, const int* n_user
     HIP_TRY(hipStreamSynchronize(s));
     if (status[0]) return fail(VET_ERR_RANGE, "Normalized coordinates must be between 0 and 1 (%d samples)", status[0]);
     if (status[1]) return fail(VET_ERR_EMPTY, "%d frame(s) without any user (Empty vector dictionary)", status[1]);
+    return VET_OK;
+}
+
+// Transition batch with concatenated host buffers: video v's samples start at element sum_{w<v} U_w*T_w of h_mu / h_mv,
+// its rows at sum_{w<v} (T_w-1) of h_entropy / h_common and its pairs at 2 * sum_{w<v} U_w*(T_w-1) of h_pairs.  Synchronous.
+int vet_transition_entropy_batch_host(vet_plan* pl, int n_videos, const int* n_users, const int* n_frames,
+                                      const double* h_mu, const double* h_mv, double* h_entropy, int32_t* h_pairs,
+                                      int32_t* h_common) {
+    if (!pl || n_videos <= 0 || !n_users || !n_frames || !h_mu || !h_mv || !h_entropy)
+        return fail(VET_ERR_INVALID, "bad batch arguments");
+    vet_ctx* c = pl->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    size_t S = 0, R = 0, P = 0;
+    for (int v = 0; v < n_videos; ++v) {
+        if (n_users[v] <= 0 || n_frames[v] <= 1) return fail(VET_ERR_INVALID, "video %d: need users and at least two frames", v);
+        S += (size_t)n_users[v] * n_frames[v];
+        R += (size_t)n_frames[v] - 1;
+        P += (size_t)n_users[v] * (n_frames[v] - 1) * 2;
+    }
+    void *mu = nullptr, *mv = nullptr, *ent = nullptr, *pr = nullptr, *cm = nullptr, *st = nullptr;
+    POOL(0, S * 8, mu); POOL(1, S * 8, mv); POOL(2, R * 8, ent);
+    if (h_pairs) POOL(3, P * 4, pr);
+    if (h_common) POOL(5, R * 4, cm);
+    POOL(6, 8, st);
+    HIP_TRY(hipMemcpyAsync(mu, h_mu, S * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(mv, h_mv, S * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(st, 0, 8, s));
+    std::vector<vet_video> vids(n_videos);
+    size_t so = 0, ro = 0, po = 0;
+    for (int v = 0; v < n_videos; ++v) {
+        vids[v].d_mu = (const double*)mu + so; vids[v].d_mv = (const double*)mv + so;
+        vids[v].n_users = n_users[v]; vids[v].n_frames = n_frames[v];
+        vids[v].d_entropy = (double*)ent + ro;
+        vids[v].d_assign = pr ? (int32_t*)pr + po : nullptr;
+        vids[v].d_present = cm ? (int32_t*)cm + ro : nullptr;
+        so += (size_t)n_users[v] * n_frames[v];
+        ro += (size_t)n_frames[v] - 1;
+        po += (size_t)n_users[v] * (n_frames[v] - 1) * 2;
+    }
+    int rc = vet_transition_entropy_batch(pl, n_videos, vids.data(), (int32_t*)st, s);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    int32_t status[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h_entropy, ent, R * 8, hipMemcpyDeviceToHost, s));
+    if (h_pairs) HIP_TRY(hipMemcpyAsync(h_pairs, pr, P * 4, hipMemcpyDeviceToHost, s));
+    if (h_common) HIP_TRY(hipMemcpyAsync(h_common, cm, R * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(status, st, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (status[0]) return fail(VET_ERR_RANGE, "Normalized coordinates must be between 0 and 1 (%d samples)", status[0]);
+    if (status[1]) return fail(VET_ERR_EMPTY, "%d frame pair(s) without a user present in both frames", status[1]);
     return VET_OK;
 }
 

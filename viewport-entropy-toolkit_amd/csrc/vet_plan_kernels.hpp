@@ -76,6 +76,22 @@ __global__ void k_finalize(const double* __restrict__ ent_k, int K, long rows, d
     }
 }
 
+// the same for a batch of videos: per-lattice values in [K][rows] (the videos' frames back to back, video v's from
+// frame0[v]), the mean goes to every video's own output
+__global__ void k_finalize_batch(const double* __restrict__ ent_k, int K, long rows, const long* __restrict__ frame0,
+                                 double* const* __restrict__ outs, int n_videos) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < rows; i += (long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n_videos - 1;                         // last video with frame0 <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (frame0[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += ent_k[(long)k * rows + i];
+        outs[lo][i - frame0[lo]] = s / (double)K;
+    }
+}
+
 // the same for the frames of a resolve list only ([0] = count, then the frames)
 __global__ void k_finalize_list(const double* __restrict__ ent_k, int K, long rows, const uint32_t* __restrict__ list,
                                 double* __restrict__ out) {

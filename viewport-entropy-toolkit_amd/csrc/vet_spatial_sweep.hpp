@@ -44,6 +44,8 @@ struct SpatialParams {
     int norm_n;                   // tile count the user count is compared with (= n except binned lattices)
     int full_norm;                // unweighted kernels: always normalise by log2(n) (binned lattices
                                   // with use_weight_distribution, entropy_utils.py:442-447)
+    const struct VideoDesc* videos;   // k_spatial_u_lds: a batch of videos in one launch (null: the single video above)
+    int n_videos, n_blocks;
     const uint32_t* frame_list;   // precise sweep as the table kernel's resolver: [0] = number of frames, then the
                                   // frames (any order); null = all T frames, blockIdx.x * FPW onwards
 };

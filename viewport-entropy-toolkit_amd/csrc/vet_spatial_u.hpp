@@ -153,18 +153,40 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
     for (int i = tid; i < FB * p.n; i += blockDim.x) cnt[i] = 0u;
     __syncthreads();
     bool bad = false;
-    const int ipf = PAIRS ? p.U >> 1 : p.U;                                      // items (pairs or users) per frame
-    const float inv_ipf = 1.0f / (float)ipf;
-    const long nblocks = ((long)p.T + FB - 1) / FB;
+    // the video and frames of a block: the launch's only video, or one of a batch (vet_spatial_entropy_batch: block0 = the
+    // video's first block, FPW = its frames per block; every video's U fits the launch's LDS tables)
+    struct Blk { const double* mu; const double* mv; int U, ipf, nf; long f0; double* ent; int32_t* assign; int32_t* present; double* weights; float inv_ipf; };
+    const long nblocks = p.videos ? (long)p.n_blocks : ((long)p.T + FB - 1) / FB;
+    auto locate = [&](long blk) {
+        Blk x;
+        x.mu = p.src.mu; x.mv = p.src.mv; x.U = p.U; x.ent = p.ent_k; x.assign = p.assign; x.present = p.present; x.weights = p.weights;
+        int T = p.T, fb = FB;
+        if (p.videos) {
+            int lo = 0, hi = p.n_videos - 1;                   // last video with block0 <= blk
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if ((long)p.videos[mid].block0 <= blk) lo = mid; else hi = mid - 1;
+            }
+            const VideoDesc& d = p.videos[lo];
+            x.mu = d.mu; x.mv = d.mv; x.U = d.U; T = d.T; fb = d.FPW;
+            x.ent = d.entropy; x.assign = d.assign; x.present = d.present; x.weights = nullptr;
+            blk -= d.block0;
+        }
+        x.f0 = blk * fb;
+        x.nf = (int)min((long)fb, (long)T - x.f0);
+        x.ipf = PAIRS ? x.U >> 1 : x.U;                        // items (pairs or users) per frame
+        x.inv_ipf = 1.0f / (float)x.ipf;
+        return x;
+    };
     // PAIRS: the next round's samples are requested before the barriers of this round (the barriers
     // wait for LDS traffic only, see lds_barrier), so HBM loads stay in flight while the waves
     // reduce the round's histograms.
     double2 a[PPT], b[PPT];
     if (PAIRS && (long)blockIdx.x < nblocks) {
-        const long f0 = (long)blockIdx.x * FB;
-        const int nitems = (int)min((long)FB, (long)p.T - f0) * ipf;
-        const double2* mu2 = (const double2*)(p.src.mu + f0 * (long)p.U);
-        const double2* mv2 = (const double2*)(p.src.mv + f0 * (long)p.U);
+        const Blk x = locate(blockIdx.x);
+        const int nitems = x.nf * x.ipf;
+        const double2* mu2 = (const double2*)(x.mu + x.f0 * (long)x.U);
+        const double2* mv2 = (const double2*)(x.mv + x.f0 * (long)x.U);
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int i = tid + k * (int)blockDim.x;
@@ -172,11 +194,13 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
         }
     }
     for (long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        const long f0 = blk * FB;
-        const int nf = (int)min((long)FB, (long)p.T - f0);
+        const Blk cur = locate(blk);
+        const long f0 = cur.f0;
+        const int nf = cur.nf, ipf = cur.ipf;
+        const float inv_ipf = cur.inv_ipf;
         const int nitems = nf * ipf;
         if (PAIRS) {
-            int2* out2 = (int2*)(p.assign ? p.assign + f0 * (long)p.U : nullptr);
+            int2* out2 = (int2*)(cur.assign ? cur.assign + f0 * (long)cur.U : nullptr);
             int near[PPT][2];
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
@@ -192,10 +216,10 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
             // next round's loads go out ahead of this round's stores
             const long nb = blk + gridDim.x;
             if (nb < nblocks) {
-                const long g0 = nb * FB;
-                const int nnext = (int)min((long)FB, (long)p.T - g0) * ipf;
-                const double2* mu2 = (const double2*)(p.src.mu + g0 * (long)p.U);
-                const double2* mv2 = (const double2*)(p.src.mv + g0 * (long)p.U);
+                const Blk nx = locate(nb);
+                const int nnext = nx.nf * nx.ipf;
+                const double2* mu2 = (const double2*)(nx.mu + nx.f0 * (long)nx.U);
+                const double2* mv2 = (const double2*)(nx.mv + nx.f0 * (long)nx.U);
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
                     const int i = tid + k * (int)blockDim.x;
@@ -214,9 +238,9 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
                 }
             }
         } else {
-            const double* mu1 = p.src.mu + f0 * (long)p.U;
-            const double* mv1 = p.src.mv + f0 * (long)p.U;
-            int* out1 = p.assign ? p.assign + f0 * (long)p.U : nullptr;
+            const double* mu1 = cur.mu + f0 * (long)cur.U;
+            const double* mv1 = cur.mv + f0 * (long)cur.U;
+            int* out1 = cur.assign ? cur.assign + f0 * (long)cur.U : nullptr;
             double a[2 * PPT], b[2 * PPT];
 #pragma unroll
             for (int k = 0; k < 2 * PPT; ++k) {
@@ -244,7 +268,7 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
             np = wave_sum(np);
             const double tw = (double)np, lgn = lg[np], inv_tw = 1.0 / tw;
             double h = 0.0;
-            double* wout = WEIGHTS ? p.weights + (f0 + f) * (long)p.n : nullptr;
+            double* wout = WEIGHTS ? cur.weights + (f0 + f) * (long)p.n : nullptr;
             for (int t = lane; t < p.n; t += WAVE) {
                 const unsigned v = row[t];
                 if (v) h -= ((double)v * inv_tw) * (lg[v] - lgn);
@@ -260,8 +284,8 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
                     e = __builtin_nan("");
                     if (p.status) atomicAdd(&p.status[1], 1);
                 }
-                p.ent_k[f0 + f] = e;
-                if (p.present) p.present[f0 + f] = np;
+                cur.ent[f0 + f] = e;
+                if (cur.present) cur.present[f0 + f] = np;
             }
         }
         lds_barrier();

@@ -35,6 +35,20 @@ struct TransParams {
     int hs_shift;                 // 32 - log2(HS)
     uint32_t* scratch;            // k_transition_any: per-workgroup slices of 3*HS + 2*U words
     int run_q, run_r;             // k_transition_run: rows per workgroup (quotient, remainder)
+    const struct TransVideo* videos;   // k_transition_run: a batch of videos in one launch (null: the single video above)
+    int n_videos;
+};
+
+// One video of a batched transition launch (vet_transition_entropy_batch): workgroups [wg0, wg0 + n_wgs) walk its
+// rows in contiguous runs of run_q (+1 for the first run_r of them) rows; a run never crosses into another video.
+struct TransVideo {
+    const double* mu;
+    const double* mv;
+    int U, T;
+    double* ent;                  // [T-1]
+    int32_t* pairs;               // [(T-1)*U*2] or null
+    int32_t* common;              // [T-1] or null
+    int wg0, n_wgs, run_q, run_r;
 };
 
 // Per-tile words of one row in LDS (both transition kernels):
@@ -236,8 +250,23 @@ __device__ __forceinline__ int grid_dir_sel(double m, double v, int W, int H, bo
 // EXACT: U == UPT * blockDim, no bounds checks on the user index; THREADS: the workgroup size when it is a
 // compile-time constant (0: read blockDim)
 template <bool FROM_IDS, int UPT, bool EXACT, int THREADS>
-__global__ void k_transition_run(const TransParams p) {
+__global__ void k_transition_run(const TransParams launch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TransParams p = launch;
+    long b = blockIdx.x;
+    if (!FROM_IDS && launch.videos) {              // this workgroup's video of the batch
+        int lo = 0, hi = launch.n_videos - 1;      // last video with wg0 <= blockIdx.x
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (launch.videos[mid].wg0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        const TransVideo& v = launch.videos[lo];
+        if ((int)blockIdx.x >= v.wg0 + v.n_wgs) return;
+        p.src.mu = v.mu; p.src.mv = v.mv; p.U = v.U; p.T = v.T;
+        p.ent_k = v.ent; p.pairs = v.pairs; p.common = v.common; p.srccount = nullptr;
+        p.run_q = v.run_q; p.run_r = v.run_r;
+        b -= v.wg0;
+    }
     double* acc2 = (double*)smem;                              // [2][TRANS_ACC]
     unsigned* first_u = (unsigned*)(acc2 + 2 * TRANS_ACC);     // [n4]
     const int n4 = (p.n + 3) & ~3;
@@ -251,7 +280,6 @@ __global__ void k_transition_run(const TransParams p) {
     const int BD = THREADS ? THREADS : (int)blockDim.x;
     const long R = (long)p.T - 1;
     // runs of run_q or run_q + 1 rows (the first run_r workgroups take the longer ones): R = run_q * gridDim + run_r
-    const long b = blockIdx.x;
     const long r_begin = b * p.run_q + (b < p.run_r ? b : (long)p.run_r);
     const long r_end = r_begin + p.run_q + (b < p.run_r ? 1 : 0);
     if (r_begin >= r_end || r_end > R) return;

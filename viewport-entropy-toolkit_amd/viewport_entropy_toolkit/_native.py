@@ -98,6 +98,8 @@ SIGNATURES = {
     "vet_transition_entropy_ids": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vet_spatial_entropy_batch": (_I, [_P, _I, _P, _P, _P]),
     "vet_spatial_entropy_batch_host": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "vet_transition_entropy_batch": (_I, [_P, _I, _P, _P, _P]),
+    "vet_transition_entropy_batch_host": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "vet_spatial_entropy_host": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "vet_transition_entropy_host": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "vet_spatial_entropy_host_resident": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, C.POINTER(_P)]),
@@ -486,6 +488,36 @@ class Plan:
             so += t * u
             ro += t
         return out
+
+    def transition_batch(self, videos, want_pairs=False, check=True):
+        """Transition mode, many videos, one launch per lattice.  ``videos``: sequence of (mu[T,U], mv[T,U]), T >= 2.
+        Returns a list of dict(entropy[T-1], pairs[T-1,U,2]|None, common[T-1]) in the same order."""
+        mus = [np.ascontiguousarray(m, dtype=np.float64) for m, _ in videos]
+        mvs = [np.ascontiguousarray(v, dtype=np.float64) for _, v in videos]
+        T = np.asarray([m.shape[0] for m in mus], dtype=np.int32)
+        U = np.asarray([m.shape[1] for m in mus], dtype=np.int32)
+        mu = np.concatenate([m.ravel() for m in mus])
+        mv = np.concatenate([v.ravel() for v in mvs])
+        R = int((T - 1).sum())
+        ent = np.empty(R, dtype=np.float64)
+        common = np.empty(R, dtype=np.int32)
+        pairs = np.empty(int(((T - 1) * U).sum()) * 2, dtype=np.int32) if want_pairs else None
+        rc = self.lib.vet_transition_entropy_batch_host(self.handle, len(mus), _ptr(U), _ptr(T), _ptr(mu), _ptr(mv),
+                                                        _ptr(ent), _ptr(pairs), _ptr(common))
+        if rc not in (VET_OK, VET_ERR_EMPTY, VET_ERR_RANGE) or (check and rc != VET_OK):
+            _check(self.lib, rc)
+        out, po, ro = [], 0, 0
+        for t, u in zip(T.tolist(), U.tolist()):
+            out.append(dict(entropy=ent[ro:ro + t - 1], common=common[ro:ro + t - 1],
+                            pairs=pairs[po:po + (t - 1) * u * 2].reshape(t - 1, u, 2) if want_pairs else None))
+            po += (t - 1) * u * 2
+            ro += t - 1
+        return out
+
+    def transition_batch_device(self, videos, d_status: int = 0, stream=None):
+        """``videos``: ctypes array of ``Video`` (device pointers: d_entropy [T-1], d_assign = pairs, d_present = common)."""
+        _check(self.lib, self.lib.vet_transition_entropy_batch(self.handle, len(videos), videos, d_status or None,
+                                                               _stream(stream)))
 
     def spatial_batch_device(self, videos, d_status: int = 0, stream=None):
         """``videos``: ctypes array of ``Video`` (device pointers); asynchronous on ``stream``
