@@ -130,11 +130,12 @@ def cpu_baseline(mu, mv, tcs, mode, weighted, budget_s):
            "reference_python": "viewport-entropy-toolkit itself, 1 core of a Xeon 2.1 GHz (BASELINE.md): "
                                "753 samples/s spatial at 51 tiles, 144 pair-samples/s transition at 201 tiles"}
     if mode == "spatial":
-        share = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         if share > 1:
             f2, d2 = timed(share, budget_s * 0.4)
             out["all_cores"] = {"value": f2 * U / d2, "unit": "samples/s", "cores": share,
-                                "sample": f"first {f2} frames, OpenMP over frames, {d2:.1f} s"}
+                                "sample": f"first {f2} frames, OpenMP over frames on every core this process may use "
+                                          f"(sched_getaffinity: {share} of {os.cpu_count()}), {d2:.1f} s"}
             c_port.set_threads(1)
     return out
 
@@ -309,6 +310,38 @@ def main():
             step()
         fence()
         elapsed = time.perf_counter() - t0
+    # ---- outside the timed region: what a step's time is made of on THIS rank (kernel time from the engine's
+    # hipEvents above; the RCCL gather alone, hipEvents around an in-order gather of the step's series)
+    gather_ms = None
+    if multi:
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        with torch.cuda.stream(run_stream):
+            fence()
+            g0.record(run_stream)
+            for _ in range(reps):
+                buf = send_bufs[0] if n_batch == 1 else ents[0]
+                dist.gather(buf if backend == "nccl" else buf.cpu(), gathered, dst=0)
+            g1.record(run_stream)
+            fence()
+        gather_ms = g0.elapsed_time(g1) / reps
+    # the practical ceiling beside the 8 TB/s nominal: a device-to-device copy that moves the workload's algorithmic
+    # bytes (read + write), timed once with hipEvents
+    copy_gbps = None
+    if rank == 0:
+        alg_probe = int((16 + (4 if mode == "spatial" else 8)) * U * T + 8 * R)
+        half = max(alg_probe // 2 // 8, 1)
+        src_c = torch.empty(half, dtype=torch.float64, device=dev).fill_(1.0)
+        dst_c = torch.empty_like(src_c)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = None
+        for _ in range(4):
+            c0.record(); dst_c.copy_(src_c); c1.record()
+            torch.cuda.synchronize()
+            t = c0.elapsed_time(c1)
+            best = t if best is None else min(best, t)
+        copy_gbps = 2.0 * half * 8 / (best * 1e-3) / 1e9
+        del src_c, dst_c
     kname = "k_spatial" if mode == "spatial" else "k_transition"
     if mode == "transition":
         formulation = "k_transition: nearest-tile LUT gather + LDS bucket statistics"
@@ -323,7 +356,13 @@ def main():
     fin_ms, fin_n = eng.profile_get("k_finalize")
     eng.profile_enable(False)
 
+    per_rank = None
     if multi:
+        # one small all_gather after the timed region: [step time, kernel time per step, gather alone] of every rank
+        mine = torch.tensor([elapsed / args.steps * 1e3, (k_ms + fin_ms) / args.steps, gather_ms or 0.0], dtype=torch.float64, device=cdev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = torch.stack(allr).cpu().numpy()
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -374,6 +413,9 @@ def main():
             "frames_per_s": (T_total if strong else R * world) * n_batch / (ms_per_step * 1e-3),
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+                         "measured_copy_ceiling": {"GBps": copy_gbps, "what": "device-to-device copy moving the workload's "
+                                                   "algorithmic bytes (read + write), hipEvent-timed outside the timed region",
+                                                   "frac_of_copy": (achieved / copy_gbps) if (achieved and copy_gbps) else None},
                          "traffic": traffic, "traffic_provenance": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "avg_kernel_ms": avg_kernel_ms, "launches": k_n,
@@ -386,6 +428,15 @@ def main():
             "formulation": formulation,
             "plan_build_ms": plan_ms,
         }
+        if per_rank is not None:
+            # attribution of a scaling point: per-rank step / kernel / gather times (ms) and their spread
+            out["per_rank"] = {"step_ms": per_rank[:, 0].tolist(), "kernel_ms": per_rank[:, 1].tolist(),
+                               "gather_ms": per_rank[:, 2].tolist(),
+                               "step_ms_max_over_min": float(per_rank[:, 0].max() / max(per_rank[:, 0].min(), 1e-9)),
+                               "kernel_ms_max_over_min": float(per_rank[:, 1].max() / max(per_rank[:, 1].min(), 1e-9)),
+                               "gather": f"one {'RCCL' if backend == 'nccl' else backend} gather of {Rg} FP64 per rank and step"
+                                         + (", overlapped with the next step's kernel inside the timed region" if pipelined else ""),
+                               "note": "gather_ms is the gather alone (in order, after the timed region); step_ms is each rank's own clock"}
         # besides the HBM figure, say what the run formulation is really bound by
         if mode == "spatial" and weighted and k_n:
             n_lat = [2 * (tc // 2) + 1 for tc in tcs]

@@ -41,6 +41,12 @@ def _worker(rank, world, port, case, q):
             got = _dist.transition_frame_sharded(mu, mv, compute)
             if rank == 0:
                 q.put(("frames", bool(np.array_equal(got, compute(mu, mv)))))
+        elif case == "sframes":
+            mu, mv = _synthetic.random_walk_video(10, 41, base_seed=4, p_absent=0.1)
+            compute = lambda a, b: vo.spatial_series(a, b, 100, 200, [20, 50])[0]  # noqa: E731
+            got = _dist.spatial_frame_sharded(mu, mv, compute)
+            if rank == 0:
+                q.put(("sframes", bool(np.array_equal(got, compute(mu, mv)))))
         elif case == "fixed":
             s = np.arange(7, dtype=np.float64) + 100 * rank
             got = _dist.gather_series(s, max_len=7)
@@ -52,7 +58,8 @@ def _worker(rank, world, port, case, q):
 
 @pytest.mark.parametrize("case,world", [("videos", 2), ("frames", 2), ("fixed", 2),
                                         # uneven shards: 5 videos / 40 rows over 3 ranks, 8 ranks with more ranks than videos
-                                        ("videos", 3), ("frames", 3), ("videos", 8), ("frames", 8)])
+                                        ("videos", 3), ("frames", 3), ("videos", 8), ("frames", 8),
+                                        ("sframes", 2), ("sframes", 3), ("sframes", 8)])
 def test_ranks_gloo(case, world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

@@ -173,7 +173,7 @@ def test_device_pointer_calls_on_torch_streams():
     assert q.get(timeout=10) == (True, True, True)
 
 
-@pytest.mark.parametrize("workload,shard", [("config2", "videos"), ("config5", "frames")])
+@pytest.mark.parametrize("workload,shard", [("config2", "videos"), ("config5", "frames"), ("config4", "videos"), ("config2", "frames")])
 def test_bench_launches_its_own_ranks(workload, shard):
     """`python bench.py --gpus 2` with no outer launcher: two ranks, n_gpus = 2 in the line (gloo rehearsal on
     one device; the driver's multi-GPU runs use RCCL, one rank per GPU)."""
@@ -188,6 +188,10 @@ def test_bench_launches_its_own_ranks(workload, shard):
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["value"] > 0
     assert rec["scaling"] == ("strong" if shard == "frames" else "weak")
+    pr = rec["per_rank"]            # attribution of a scaling point: every rank's step / kernel / gather time
+    assert len(pr["step_ms"]) == len(pr["kernel_ms"]) == len(pr["gather_ms"]) == 2
+    assert all(k > 0 for k in pr["kernel_ms"]) and all(g > 0 for g in pr["gather_ms"])
+    assert pr["step_ms_max_over_min"] >= 1.0
 
 
 @pytest.mark.parametrize("workload", ["config2", "config5"])
@@ -208,6 +212,10 @@ def test_bench_rccl_pipelined_gather(workload):
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["value"] > 0
+    pr = rec["per_rank"]
+    assert len(pr["step_ms"]) == 1 and pr["kernel_ms"][0] > 0 and pr["gather_ms"][0] > 0
+    assert pr["kernel_ms"][0] <= rec["ms_per_step"] * 1.001          # the kernel is inside the step
+    assert rec["roofline"]["measured_copy_ceiling"]["GBps"] > 1000
 
 
 def _engine_then_torch_worker(q):

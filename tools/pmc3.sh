@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: tools/pmc3.sh <workload> <tag>  — stall-oriented counter passes (TCP / TA / TD / TCC / LDS) for the dominant kernel.
-# At most four counters of one hardware block per pass (more aborts rocprofv3 on gfx950), every pass under its own timeout.
+# At most four counters of one TCP / TA / TD / TCC block per pass (more aborts rocprofv3 on gfx950; the SQ block took the six
+# of the last pass, profiles/r02/config3_pmc_stalls.json has all of them), every pass under its own timeout.
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"
 W=$1; TAG=$2

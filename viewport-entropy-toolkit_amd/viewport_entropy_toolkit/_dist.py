@@ -122,6 +122,23 @@ def transition_frame_sharded(mu: np.ndarray, mv: np.ndarray, compute: Callable[[
     return np.concatenate(got) if got is not None else None
 
 
+def spatial_frame_sharded(mu: np.ndarray, mv: np.ndarray, compute: Callable[[np.ndarray, np.ndarray], np.ndarray],
+                          dst: int = 0, device=None):
+    """One video across all ranks in spatial mode (strong scaling): frames are independent
+    (entropy_utils.py:147-211 touches one row), so each rank computes a contiguous block of frames
+    (``frame_shard``, no halo) and ONE gather concatenates the blocks on ``dst``."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    T = mu.shape[0]
+    f0, f1 = frame_shard(T, rank, world)
+    part = compute(mu[f0:f1], mv[f0:f1]) if f1 > f0 else np.empty(0)
+    base, extra = divmod(T, world)
+    got = gather_series(part, dst=dst, max_len=base + (1 if extra else 0), device=device)
+    return np.concatenate(got) if got is not None else None
+
+
 def analyze_directories(directories: Sequence, config=None, mode: str = "spatial", dst: int = 0, device=None):
     """One video directory per GPU at a time (README.md:108-120 of the reference suggests a process
     pool; here it is one process per GPU under ``torch.distributed.run``).  Every rank builds its own
