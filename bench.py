@@ -130,13 +130,19 @@ def cpu_baseline(mu, mv, tcs, mode, weighted, budget_s):
            "reference_python": "viewport-entropy-toolkit itself, 1 core of a Xeon 2.1 GHz (BASELINE.md): "
                                "753 samples/s spatial at 51 tiles, 144 pair-samples/s transition at 201 tiles"}
     if mode == "spatial":
-        share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        if share > 1:
-            f2, d2 = timed(share, budget_s * 0.4)
-            out["all_cores"] = {"value": f2 * U / d2, "unit": "samples/s", "cores": share,
-                                "sample": f"first {f2} frames, OpenMP over frames on every core this process may use "
-                                          f"(sched_getaffinity: {share} of {os.cpu_count()}), {d2:.1f} s"}
-            c_port.set_threads(1)
+        aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        # every core this process may use; a GPU box hands a one-GPU job a CPU share (16 cores) of a 256-core host through
+        # its cgroup, where 256 threads only fight each other — both thread counts are timed, the faster one is reported
+        tried = []
+        for share in sorted({min(16, aff), aff}):
+            if share > 1:
+                f2, d2 = timed(share, budget_s * 0.2)
+                tried.append({"value": f2 * U / d2, "unit": "samples/s", "cores": share,
+                              "sample": f"first {f2} frames, OpenMP over frames, {d2:.1f} s"})
+        c_port.set_threads(1)
+        if tried:
+            best = max(tried, key=lambda r: r["value"])
+            out["all_cores"] = dict(best, affinity_cpus=aff, host_cpus=os.cpu_count(), thread_counts_tried=tried)
     return out
 
 

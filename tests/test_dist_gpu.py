@@ -215,7 +215,7 @@ def test_bench_rccl_pipelined_gather(workload):
     pr = rec["per_rank"]
     assert len(pr["step_ms"]) == 1 and pr["kernel_ms"][0] > 0 and pr["gather_ms"][0] > 0
     assert pr["kernel_ms"][0] <= rec["ms_per_step"] * 1.001          # the kernel is inside the step
-    assert rec["roofline"]["measured_copy_ceiling"]["GBps"] > 1000
+    assert rec["roofline"]["measured_copy_ceiling"]["GBps"] > 100       # 3.8 MB at config 2: a launch-bound copy
 
 
 def _engine_then_torch_worker(q):
