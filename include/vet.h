@@ -132,7 +132,10 @@ int64_t vet_plan_n_dirs(const vet_plan *plan);
  * own rows proves their deviation from exact arithmetic <= 1e-7 relative for EVERY possible frame
  * (k_row_stats; the contract is 1e-6); plans outside that — FoV cones narrower than the lattice
  * spacing, large power factors — run `ftable` (calls large enough for a table) or `precise`; those two
- * sum in FP64 and are reproducible to ~1e-15, not bit for bit (`ftable`: LDS atomics in arrival order).
+ * sum in FP64 in a fixed order: `ftable` sorts every frame's list of distinct rows, gives every wave a histogram
+ * of its own and adds those in wave order (bit-identical run to run, under any user permutation of frames of
+ * <= 2048 users, frame split or GPU count); `precise` sums the users in column order, as the reference does
+ * (as the resolver of `ftable`: in ascending direction order).
  * The reference's NaN frames: every tile with distance < fov/2 is a key of the reference's per-frame dict,
  * also when ((max - d) / max) ** power_factor underflows to exactly 0.0 (entropy_utils.py:131-135), and a key
  * whose summed weight is 0.0 (or underflows against the frame total) makes the entropy NaN = 0 * log2 0

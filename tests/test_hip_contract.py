@@ -169,3 +169,37 @@ def test_error_bounds_of_the_baseline_plans(native, engine):
         plan.spatial(mu=np.full((2, 3), 0.4), mv=np.full((2, 3), 0.6))
         assert plan.last_formulation(0) == "ftable"
         plan.close()
+
+
+@pytest.mark.parametrize("tcs,fov,power", [([500], 10.0, 2.0), ([50], 120.0, 20.0), ([50, 100], 120.0, 30.0), ([500], 120.0, 150.0)])
+def test_fp_table_is_bit_reproducible(native, engine, tcs, fov, power):
+    """`ftable` (FP32 table weights, FP64 histograms): every frame's row list is sorted and every wave adds its rows into
+    a histogram of its own in program order, so the floats do not depend on scheduling — bit-identical run to run, under
+    any permutation of the users, under a split of the frame axis (= the GPU count).  Plans with marker entries hand
+    their undecided frames to the precise sweep, which then sums the users in ascending direction order: the same holds."""
+    U, T = 256, 1500
+    rng = np.random.default_rng(int(fov * power))
+    mu = np.mod(0.5 + np.cumsum(rng.normal(0, 0.01, (T, U)), axis=0), 1.0)
+    mv = np.clip(0.5 + np.cumsum(rng.normal(0, 0.005, (T, U)), axis=0), 0.0, 1.0)
+    plan = native.Plan(engine, [vo.fibonacci_lattice(tc) for tc in tcs], fov, power, True, W, H)
+    plan.set_table_policy(1)
+    a = plan.spatial(mu=mu, mv=mv, want_weights=True)
+    assert plan.last_formulation(0) == "ftable"
+    for _ in range(3):
+        b = plan.spatial(mu=mu, mv=mv, want_weights=True)
+        assert np.array_equal(a["entropy"], b["entropy"], equal_nan=True)
+        assert np.array_equal(a["weights"], b["weights"])
+    d = plan.spatial(mu=mu[377:1201], mv=mv[377:1201], want_assign=False)
+    assert np.array_equal(d["entropy"], a["entropy"][377:1201], equal_nan=True)
+    perm = rng.permutation(U)
+    c = plan.spatial(mu=mu[:, perm], mv=mv[:, perm], want_assign=False)
+    assert np.array_equal(c["entropy"], a["entropy"], equal_nan=True)
+    few = plan.spatial(mu=mu[:40, :100], mv=mv[:40, :100])          # fewer than 128 users: no set of distinct rows
+    few2 = plan.spatial(mu=mu[:40, :100][:, ::-1].copy(), mv=mv[:40, :100][:, ::-1].copy())
+    assert np.array_equal(few["entropy"], few2["entropy"], equal_nan=True)
+    frames = np.concatenate([[0, T - 1], rng.integers(0, T, 12)])
+    ent, _, _ = vo.spatial_series(mu[frames], mv[frames], W, H, tcs, fov_angle=fov, power_factor=power)
+    assert np.array_equal(np.isnan(a["entropy"][frames]), np.isnan(ent))
+    ok = ~np.isnan(ent)
+    np.testing.assert_allclose(a["entropy"][frames][ok], ent[ok], rtol=1e-6, atol=ATOL)
+    plan.close()

@@ -749,8 +749,9 @@ bool any_binned(const vet_plan* pl) {
     return false;
 }
 
-// The formulation of a weighted call is a pure function of the plan and the call's shape — never of
-// what the plan has processed before — so the same input always gives the same floats:
+// The formulation of a weighted call is a function of the plan, the call's shape and (table does not fit the free
+// device memory -> sweep) the memory left on the device — never of what the plan has processed before — and every
+// formulation adds in a fixed order, so the same input gives the same floats:
 //   table    policy +1, or policy 0 and the call holds at least 8 samples per direction of the table
 //            (building a row costs about what the sweep spends on 30 samples; a gathered sample is ~6x
 //            cheaper than a swept one), if the table fits and its error bound is inside the contract;
@@ -832,19 +833,21 @@ int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& sr
     int blocks = blocks_batch, threads = 256;
     size_t lds = lds_batch;
     bool occ8 = true;
+    // FP table: canonical row order through a bitmap over (row, mirrored) where that is small (<= 8 KB of LDS)
+    q.sort_words = (fpt && dedup && 2 * pl->n_dirs <= 65536) ? (int)((2 * pl->n_dirs + 31) / 32) : 0;
     if (!d_videos) {
         q.UC = U < 2048 ? U : 2048;
+        threads = fpt ? 256 : env_threads("VET_LUT_THREADS", threads);     // the FP table's row sort counts on 256 threads
+        if (threads > 256) threads = 256;         // __launch_bounds__(256)
         int fpw = lut_frames_per_wg(U, T, c->n_cu, q.n_sum);
         fpw = env_int("VET_LUT_FPW", 1, 16, fpw);
         for (;; fpw /= 2) {
-            lds = vet::lut_lds_bytes(U, q.UC, fpw, q.n_sum, dedup, d_resolve != nullptr);
+            lds = vet::lut_lds_bytes(U, q.UC, fpw, q.n_sum, dedup, d_resolve != nullptr, fpt ? threads / 64 : 1, q.sort_words);
             if (lds <= c->lds_max || fpw == 1) break;
         }
         if (lds > c->lds_max) return VET_OK;      // not launched: caller falls back to the sweep
         q.FPW = fpw;
         blocks = (T + fpw - 1) / fpw;
-        threads = env_threads("VET_LUT_THREADS", threads);
-        if (threads > 256) threads = 256;         // __launch_bounds__(256)
         occ8 = K == 1 && threads == 256;
     } else {
         q.FPW = 1; q.UC = 1;
@@ -919,12 +922,13 @@ int launch_lut_fused(vet_plan* pl, const vet::SampleSrc& src, int U, int T, cons
 }
 
 // LDS bytes and frames per workgroup of one video of a batch (0 = does not fit)
-size_t batch_video_geometry(const vet_ctx* c, int U, long total_frames, int n_sum, bool dedup, int* fpw_out, int* uc_out) {
+size_t batch_video_geometry(const vet_ctx* c, int U, long total_frames, int n_sum, bool dedup, int* fpw_out, int* uc_out,
+                            int priv = 1, int sort_words = 0) {
     const int UC = U < 2048 ? U : 2048;
     int fpw = lut_frames_per_wg(U, total_frames, c->n_cu, n_sum);
     size_t lds = 0;
     for (;; fpw /= 2) {
-        lds = vet::lut_lds_bytes(U, UC, fpw, n_sum, dedup);
+        lds = vet::lut_lds_bytes(U, UC, fpw, n_sum, dedup, false, priv, sort_words);
         if (lds <= c->lds_max || fpw == 1) break;
     }
     *fpw_out = fpw; *uc_out = UC;
@@ -974,7 +978,9 @@ int resolve_frames(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc
         if (grid > T) grid = T;
         void* args[] = {(void*)&p};
         ProfScope ps(c, s, KID_SPATIAL);
-        HIP_TRY(hipLaunchKernel(spatial_w_kernel<FROM_IDS>(0, g.R, true), dim3((unsigned)grid), dim3(g.NW * vet::WAVE), args, g.lds, s));
+        const size_t lds = g.lds + (size_t)g.UC * 4 + 16;        // + the users' direction ids (canonical order of the sums)
+        if (lds > c->lds_max) return fail(VET_ERR_UNSUPPORTED, "resolver: %zu B of LDS", lds);
+        HIP_TRY(hipLaunchKernel(spatial_w_kernel<FROM_IDS>(0, g.R, true), dim3((unsigned)grid), dim3(g.NW * vet::WAVE), args, lds, s));
     }
     if (K > 1) {
         ProfScope ps(c, s, KID_FINALIZE);
@@ -1858,7 +1864,8 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
             vet::VideoDesc& d = desc[v];
             d.mu = x.d_mu; d.mv = x.d_mv; d.U = x.n_users; d.T = x.n_frames;
             d.entropy = x.d_entropy; d.assign = x.d_assign; d.present = x.d_present;
-            const size_t lds = batch_video_geometry(c, d.U, total_frames, n_sum, dedup, &d.FPW, &d.UC);
+            const size_t lds = batch_video_geometry(c, d.U, total_frames, n_sum, dedup, &d.FPW, &d.UC, form0 == F_FTABLE ? 4 : 1,
+                                                    (form0 == F_FTABLE && dedup && 2 * pl->n_dirs <= 65536) ? (int)((2 * pl->n_dirs + 31) / 32) : 0);
             if (lds == 0) table = false;
             d.block0 = block; d.pad_ = 0;
             block += (d.T + d.FPW - 1) / d.FPW;

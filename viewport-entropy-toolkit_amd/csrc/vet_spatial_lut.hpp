@@ -239,6 +239,7 @@ struct LutParams {
     int32_t* present;
     int32_t* status;
     int FPW, UC;
+    int sort_words;               // FPT: words of the (row, mirrored) bitmap that orders a frame's distinct rows (0: rank sort)
     FusedLayout lay;              // FUSED: the launch's one "lattice" is the plan's fused table (n = lay.N slots)
     unsigned long long* dbg;      // VET_LUT_DEBUG (FUSED): [4] cycles of thread 0 per stage, summed over the workgroups
     uint32_t* resolve;            // FP tables with marker entries: [0] = number of frames handed to the precise sweep
@@ -253,9 +254,16 @@ __host__ __device__ __forceinline__ int lut_hash_slots(int UC) {
 }
 // LDS bytes of a workgroup; the kernel and the host must agree
 __host__ __device__ __forceinline__ int lut_marked_words(int n_sum) { return (n_sum + 31) >> 5; }
-__host__ __device__ __forceinline__ size_t lut_lds_bytes(int U, int UC, int FPW, int n_sum, bool dedup, bool marked = false) {
-    const size_t hist = (size_t)FPW * n_sum * 8, hash = dedup ? (size_t)FPW * lut_hash_slots(UC) * 4 : 0;
-    const size_t a = (dedup && U <= UC) ? (hist > hash ? hist : hash) : hist + hash;
+// priv: histograms per frame — 1, or one per wave for FP tables (each wave adds its rows of the SORTED row list into its
+// own histogram in program order, the histograms are added in wave order: FP64 sums that do not depend on scheduling)
+// sort_words: FP tables put every frame's row list into a canonical order through a bitmap over (row, mirrored); the bitmap
+// (+ 256 scan words) lives in the histogram / set region too (the histograms are cleared after the sort)
+__host__ __device__ __forceinline__ size_t lut_lds_bytes(int U, int UC, int FPW, int n_sum, bool dedup, bool marked = false,
+                                                         int priv = 1, int sort_words = 0) {
+    const size_t hist = (size_t)FPW * n_sum * 8 * priv, hash = dedup ? (size_t)FPW * lut_hash_slots(UC) * 4 : 0;
+    const size_t srt = sort_words ? ((size_t)sort_words + 256) * 4 : 0;
+    size_t a = (dedup && U <= UC) ? (hist > hash ? hist : hash) : hist + hash;
+    if (dedup && U <= UC && srt > a) a = srt;
     return ((a + 15) & ~(size_t)15) + (size_t)FPW * UC * 8 + (size_t)2 * FPW * 4 + 64 +
            (marked ? (size_t)FPW * lut_marked_words(n_sum) * 4 : 0);
 }
@@ -272,7 +280,7 @@ __host__ __device__ __forceinline__ size_t lut_lds_bytes(int U, int UC, int FPW,
 // histogram slots instead of tiles, the exact total of every lattice in its total slots; the epilogue reads the
 // lattices back out of the fused histogram.
 template <bool FROM_IDS, int UN, bool IL, bool OCC8, bool DEDUP, bool FPT, bool FUSED = false>
-__global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutParams p) {
+__global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(const LutParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // the video this workgroup works on: the launch's only one, or one of a batch
     SampleSrc src = p.src;
@@ -296,8 +304,11 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
     }
     const int HS = DEDUP ? lut_hash_slots(UC) : 0;
     const bool overlay = DEDUP && U <= UC;                                       // one chunk: set and histogram share space
-    const size_t hist_bytes = (size_t)FPW * p.n_sum * 8, hash_bytes = (size_t)FPW * HS * 4;
-    const size_t a_bytes = overlay ? (hist_bytes > hash_bytes ? hist_bytes : hash_bytes) : hist_bytes + hash_bytes;
+    const int PRIV = FPT ? (int)(blockDim.x >> 6) : 1;                            // FP table: one histogram per wave
+    const size_t hist_bytes = (size_t)FPW * p.n_sum * 8 * PRIV, hash_bytes = (size_t)FPW * HS * 4;
+    const size_t sort_bytes = (FPT && overlay && p.sort_words) ? ((size_t)p.sort_words + 256) * 4 : 0;
+    size_t a_bytes = overlay ? (hist_bytes > hash_bytes ? hist_bytes : hash_bytes) : hist_bytes + hash_bytes;
+    if (sort_bytes > a_bytes) a_bytes = sort_bytes;
     unsigned long long* hist = (unsigned long long*)smem;                        // [FPW][n_sum]
     uint32_t* hash = (uint32_t*)(smem + (overlay ? 0 : hist_bytes));             // [FPW][HS]
     uint32_t* rows = (uint32_t*)(smem + ((a_bytes + 15) & ~(size_t)15));         // [FPW][UC]
@@ -315,7 +326,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
         if (FUSED && p.dbg) { const unsigned long long now = __builtin_readcyclecounter(); tdbg[i] += now - tlast; tlast = now; }
     };
     if (!overlay)
-        for (int i = tid; i < FPW * p.n_sum; i += blockDim.x) hist[i] = 0ull;
+        for (int i = tid; i < FPW * p.n_sum * PRIV; i += blockDim.x) hist[i] = 0ull;
     for (int i = tid; i < 2 * FPW; i += blockDim.x) cnt_chunk[i] = 0;
     if (FPT && marked)
         for (int i = tid; i < FPW * MW; i += blockDim.x) marked[i] = 0u;
@@ -448,9 +459,95 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
                 const int fl = i / UC, j = i - fl * UC;
                 if (j < cnt_chunk[fl]) rows[i] = hash[(size_t)fl * HS + rows[i]];
             }
-            if (overlay) {
+            if (overlay && !FPT) {
                 __syncthreads();
                 for (int i = tid; i < FPW * p.n_sum; i += blockDim.x) hist[i] = 0ull;
+            }
+        }
+        if (FPT) {
+            // FP64 sums must not depend on the order in which the users arrived: every frame's row list is put into
+            // ascending order, so that row j always goes to the same wave, lane group and turn of the walk below.
+            __syncthreads();
+            constexpr int EPT = 8;                               // UC <= 2048 rows over 256 threads
+            const bool by_bitmap = DEDUP && overlay && p.sort_words > 0;
+            for (int fl = 0; fl < nf; ++fl) {
+                const int cnt = cnt_chunk[fl];
+                uint32_t* fr = rows + (size_t)fl * UC;
+                uint32_t* fm = meta + (size_t)fl * UC;
+                uint32_t key[EPT];
+                int rank[EPT];
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const int e = tid + q * (int)blockDim.x;
+                    key[q] = e < cnt ? fr[e] : 0xFFFFFFFFu;
+                    rank[q] = 0;
+                }
+                if (by_bitmap) {
+                    // distinct rows: rank = number of set bits below the row's own bit in a bitmap over (row, mirrored)
+                    // — O(rows) instead of the O(rows^2) of a rank sort.  The bitmap sits in the histogram / set region
+                    // (the set has been read out above; the histograms are cleared after the sort).
+                    uint32_t* bm = (uint32_t*)smem;              // [SW]
+                    uint32_t* toff = bm + p.sort_words;          // [256] bits set in the words before a thread's span
+                    const int SW = p.sort_words, WPT = (SW + (int)blockDim.x - 1) / (int)blockDim.x;
+                    for (int i = tid; i < SW; i += blockDim.x) bm[i] = 0u;
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < EPT; ++q)
+                        if (tid + q * (int)blockDim.x < cnt) {
+                            const uint32_t k20 = key[q] >> 12, bit = (k20 & ROW_MASK) * 2u + ((k20 >> ROW_BITS) & 1u);
+                            atomicOr(&bm[bit >> 5], 1u << (bit & 31));
+                        }
+                    __syncthreads();
+                    int mine = 0;
+                    for (int w = tid * WPT; w < min(SW, (tid + 1) * WPT); ++w) mine += __popc(bm[w]);
+                    int incl = mine;                             // inclusive scan over the workgroup's threads
+#pragma unroll
+                    for (int o = 1; o < WAVE; o <<= 1) {
+                        const int up = __shfl_up(incl, o, WAVE);
+                        if (lane >= o) incl += up;
+                    }
+                    int* wtot = (int*)(toff + 252);              // the last four scan words double as the waves' totals
+                    __syncthreads();
+                    if (lane == WAVE - 1) wtot[wv] = incl;
+                    __syncthreads();
+                    int before = 0;
+                    for (int w2 = 0; w2 < wv; ++w2) before += wtot[w2];
+                    __syncthreads();
+                    toff[tid] = (uint32_t)(before + incl - mine);
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < EPT; ++q)
+                        if (tid + q * (int)blockDim.x < cnt) {
+                            const uint32_t k20 = key[q] >> 12, bit = (k20 & ROW_MASK) * 2u + ((k20 >> ROW_BITS) & 1u);
+                            const int w = (int)(bit >> 5), t0 = w / WPT;
+                            int r = (int)toff[t0];
+                            for (int w2 = t0 * WPT; w2 < w; ++w2) r += __popc(bm[w2]);
+                            rank[q] = r + __popc(bm[w] & ((1u << (bit & 31)) - 1u));
+                        }
+                } else {
+                    // rank sort: few rows (no set below 128 users: equal rows may repeat, their order cannot matter),
+                    // or users in several chunks
+                    for (int j = 0; j < cnt; ++j) {
+                        const uint32_t other = fr[j];            // broadcast read
+#pragma unroll
+                        for (int q = 0; q < EPT; ++q) {
+                            const int e = tid + q * (int)blockDim.x;
+                            rank[q] += (other < key[q] || (other == key[q] && j < e)) ? 1 : 0;
+                        }
+                    }
+                }
+                uint32_t mk[EPT];                                // (read only now: eight registers less across the ranking)
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) mk[q] = tid + q * (int)blockDim.x < cnt ? fm[tid + q * (int)blockDim.x] : 0u;
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < EPT; ++q)
+                    if (tid + q * (int)blockDim.x < cnt) { fr[rank[q]] = key[q]; fm[rank[q]] = mk[q]; }
+                __syncthreads();
+            }
+            if (overlay) {
+                for (int i = tid; i < FPW * p.n_sum * PRIV; i += blockDim.x) hist[i] = 0ull;
+                __syncthreads();
             }
         }
         int hoff = 0;
@@ -469,11 +566,11 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
             for (int fl = 0; fl < nf; ++fl)
                 if (IL && L.interleaved)
                     walk_rows<UN, true, DEDUP, FPT>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
-                                               hist + (size_t)fl * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
+                                               hist + ((size_t)fl * PRIV + (FPT ? wv : 0)) * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
                                                L.zrow * (uint32_t)L.stride, marked ? marked + (size_t)fl * MW : nullptr, hoff);
                 else
                     walk_rows<UN, false, DEDUP, FPT>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
-                                                hist + (size_t)fl * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
+                                                hist + ((size_t)fl * PRIV + (FPT ? wv : 0)) * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
                                                 L.zrow * (uint32_t)L.stride, marked ? marked + (size_t)fl * MW : nullptr, hoff);
             hoff += L.n;
         }
@@ -534,7 +631,13 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
         }
     } else
     for (int fl = wv; fl < nf; fl += NW) {
-        const unsigned long long* hrow = hist + (size_t)fl * p.n_sum;
+        const unsigned long long* hrow = hist + (size_t)fl * PRIV * p.n_sum;
+        // FP table: the tile's weight = the waves' histograms added in wave order
+        auto fp_value = [&](const unsigned long long* h, int t) {
+            double v = 0.0;
+            for (int w = 0; w < PRIV; ++w) v += __longlong_as_double((long long)h[(size_t)w * p.n_sum + t]);
+            return v;
+        };
         double total_entropy = 0.0;
         bool unresolved = false;           // a key of the reference's dict (marker hit) whose table weight sum is 0.0
         int bit0 = 0;
@@ -542,11 +645,11 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : 7) void k_spatial_lut(const LutPara
             const int n = p.lat[k].n;
             // total weight can exceed 64 bits of fixed point: summed in FP64, fixed lane order + butterfly
             double totd = 0.0;
-            for (int t = lane; t < n; t += WAVE) totd += FPT ? __longlong_as_double((long long)hrow[t]) : (double)hrow[t];
+            for (int t = lane; t < n; t += WAVE) totd += FPT ? fp_value(hrow, t) : (double)hrow[t];
             totd = wave_sum(totd);
             double h = 0.0;
             for (int t = lane; t < n; t += WAVE) {
-                const double v = FPT ? __longlong_as_double((long long)hrow[t]) : (double)hrow[t];
+                const double v = FPT ? fp_value(hrow, t) : (double)hrow[t];
                 if (v != 0.0) {
                     const double q = v / totd;
                     h -= q * log2(q);

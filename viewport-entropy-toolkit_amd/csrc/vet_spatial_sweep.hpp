@@ -150,6 +150,28 @@ __global__ void k_spatial_w(const SpatialParams p) {
         for (int i = tid; i < p.FPW; i += blockDim.x) cnt_chunk[i] = 0;
         __syncthreads();
         // ---- prologue: samples -> direction ids -> unit directions in LDS, nearest tile out
+        if (PRECISE && p.frame_list) {
+            // resolver of the FP table: that formulation does not depend on the order of the users, so the frames it hands
+            // over are summed in a canonical order too — users by ascending direction id (equal ids: equal weights)
+            int* ids = cnt_frame + p.FPW;                              // [UC] (the host adds UC * 4 bytes in list mode)
+            for (int i = tid; i < uc; i += blockDim.x) ids[i] = sample_dir<FROM_IDS>(p.src, f0 * (long)p.U + u0 + i, bad);
+            __syncthreads();
+            for (int i = tid; i < uc; i += blockDim.x) {
+                const int id = ids[i];
+                const unsigned key = (unsigned)id;                     // absent (-1) sorts last
+                int rank = 0;
+                for (int j = 0; j < uc; ++j) {
+                    const unsigned other = (unsigned)ids[j];
+                    rank += (other < key || (other == key && j < i)) ? 1 : 0;
+                }
+                double* dst = dirs + (size_t)rank * 3;
+                const double nan = __builtin_nan("");
+                dst[0] = id >= 0 ? p.dir_unit[3 * (long)id] : nan;
+                dst[1] = id >= 0 ? p.dir_unit[3 * (long)id + 1] : nan;
+                dst[2] = id >= 0 ? p.dir_unit[3 * (long)id + 2] : nan;
+                if (id >= 0) atomicAdd(&cnt_chunk[0], 1);
+            }
+        } else
         for (int i = tid; i < nf * uc; i += blockDim.x) {
             const int fl = i / uc, uu = i - fl * uc;
             const long idx = (f0 + fl) * (long)p.U + u0 + uu;
