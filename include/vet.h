@@ -23,9 +23,12 @@
  *     (hipStreamNonBlocking: not ordered against the null stream) — it is NOT the null stream.
  *     To run on the legacy default stream (what torch calls its default stream, handle 0) pass
  *     VET_STREAM_LEGACY; any other value is used as the hipStream_t it is.
- *     Device-pointer entry points only enqueue work; they do not synchronise.  A context is
- *     single-threaded, and calls that share its scratch (vet_spatial_entropy_batch's descriptor
- *     buffer, the K > 1 workspace) must be issued on one stream or be synchronised in between.
+ *     Device-pointer entry points only enqueue work; they do not synchronise.  A context — and
+ *     every plan of it — is single-threaded and must not be in use on two streams at once: its
+ *     scratch (the batch descriptors, the K > 1 workspace, the transition scratch, the resolve
+ *     list of an FP table) is shared by all calls, so calls on different streams must be
+ *     synchronised in between.  A plan's tables are complete (stream synchronised) when the
+ *     call that built them returns; a result handle (vet_result) may outlive its context.
  *   - there is no CPU fallback: without a gfx950 device vet_create() fails.
  */
 #ifndef VET_H_
