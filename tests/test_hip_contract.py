@@ -203,3 +203,38 @@ def test_fp_table_is_bit_reproducible(native, engine, tcs, fov, power):
     ok = ~np.isnan(ent)
     np.testing.assert_allclose(a["entropy"][frames][ok], ent[ok], rtol=1e-6, atol=ATOL)
     plan.close()
+
+
+@pytest.mark.parametrize("tcs,fov,power", [([50], 120.0, 50.0), ([50], 120.0, 20.0)])
+@pytest.mark.parametrize("policy", [1, -1])
+def test_tiny_entropies_against_extended_precision(native, engine, tcs, fov, power, policy):
+    """Where the 1e-6 relative contract meets the FP64 rounding floor of the reference's own -p*log2(p) (single-user
+    frames whose entropy is 1e-9 ... 4e-12: the ATOL term of the tests above), the comparison is made against the
+    entropy evaluated in extended precision (numpy longdouble) from the same FP64 tile weights: the engine must be
+    within 1e-6 relative of it, or at most twice as far from it as the FP64 reference path itself gets."""
+    if np.finfo(np.longdouble).eps > 1e-18:
+        pytest.skip("no extended precision on this host")
+    L = vo.fibonacci_lattice(tcs[0])
+    flat = vo.direction_grid(W, H).reshape(-1, 3)
+    rows = vo.tile_weight_rows(flat, L, fov, power)                      # FP64 weights, as the reference computes them
+    mu, mv = all_directions()
+    ld = rows.astype(np.longdouble)
+    tot = ld.sum(axis=1, keepdims=True)
+    with np.errstate(all="ignore"):
+        p_ld = ld / tot
+        h_ld = -(np.where(ld > 0, p_ld * np.log2(np.where(ld > 0, p_ld, 1)), 0)).sum(axis=1) / np.log2(np.longdouble(len(L)))
+    ref64, _ = oracle_for(tcs, fov, power, "one user", mu[:, None], mv[:, None])
+    plan = native.Plan(engine, [L], fov, power, True, W, H)
+    plan.set_table_policy(policy)
+    got = plan.spatial(mu=mu[:, None], mv=mv[:, None], want_assign=False)["entropy"]
+    plan.close()
+    ok = np.isfinite(ref64) & (h_ld > 0)
+    err_eng = np.abs(got.astype(np.longdouble) - h_ld)[ok]
+    err_ref = np.abs(ref64.astype(np.longdouble) - h_ld)[ok]
+    rel_ok = err_eng <= 1e-6 * h_ld[ok]
+    tiny = ~rel_ok
+    # the frames outside 1e-6 relative are exactly the ones where FP64 itself cannot do better
+    floor = float(err_ref.max())
+    assert floor < 1e-15
+    assert np.all(err_eng[tiny] <= 2 * floor + 1e-22), (int(tiny.sum()), float(err_eng[tiny].max()), floor)
+    assert np.all(h_ld[ok][tiny] < 1e-8)

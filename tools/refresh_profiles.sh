@@ -23,6 +23,18 @@ line config4 --workload config4 --no-cpu-baseline || exit 1
 line config2 --workload config2 --steps 50 --no-cpu-baseline || exit 1
 line config2x64 --workload config2x64 --no-cpu-baseline || exit 1
 line defaults --workload defaults --no-cpu-baseline || exit 1
+# batched launches of the nearest-tile and transition modes, and the same videos one call each
+for w in config2x64u config2x64t config5x64; do
+  line $w --workload $w --no-cpu-baseline || exit 1
+  line ${w}_loop --workload $w --loop --no-cpu-baseline || exit 1
+done
+line config2x64_loop --workload config2x64 --loop --no-cpu-baseline || exit 1
+# per-lattice tables instead of the fused one (VET_NO_FUSED=1) and the experimental persistent kernel (VET_ROWS=1)
+for w in config4 defaults config2x64; do VET_NO_FUSED=1 line ${w}_per_lattice_tables --workload $w --no-cpu-baseline --no-api || exit 1; done
+for w in config3 config4; do VET_ROWS=1 line ${w}_rows_kernel --workload $w --no-cpu-baseline --no-api || exit 1; done
+timeout -k 10 300 python3 tools/precise_timing.py > gpurun_out/$TAG/formulation_timing.txt 2>&1 || echo "formulation timing failed"
+timeout -k 10 300 python3 tools/transition_any_timing.py > gpurun_out/$TAG/transition_any_timing.txt 2>&1 || echo "transition_any timing failed"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/transition_any_trace -- python3 tools/transition_any_timing.py > /dev/null 2>&1 && cp $(ls gpurun_out/$TAG/transition_any_trace/*/*_kernel_stats.csv | head -1) gpurun_out/$TAG/transition_any_kernel_stats.csv
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/default_trace -- python3 bench.py --no-cpu-baseline --no-api > gpurun_out/$TAG/default_bench_under_rocprof.json 2> gpurun_out/$TAG/default_trace.err || { echo "rocprof default bench failed"; exit 1; }
 cp $(ls gpurun_out/$TAG/default_trace/*/*_kernel_stats.csv | head -1) gpurun_out/$TAG/default_bench_kernel_stats.csv
 for w in config3 config3u config4 config5; do cp $(ls gpurun_out/$TAG/pmc/$w/trace/*/*_kernel_stats.csv | head -1) gpurun_out/$TAG/pmc_${w}_kernel_stats.csv; done

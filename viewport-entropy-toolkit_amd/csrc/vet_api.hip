@@ -1160,6 +1160,13 @@ const void* transition_run_kernel(int upt, bool exact, int threads) {
     return nullptr;
 }
 
+const void* transition_batch_kernel(int upt, bool exact) {       // batched launches: the workgroup size is read from blockDim
+#define VET_PICK(N) if (upt == N) return exact ? (const void*)vet::k_transition_run<false, N, true, 0, true> : (const void*)vet::k_transition_run<false, N, false, 0, true>
+    VET_PICK(1); VET_PICK(2); VET_PICK(4); VET_PICK(8);
+#undef VET_PICK
+    return nullptr;
+}
+
 template <bool FROM_IDS>
 int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double* d_entropy, int32_t* d_pairs,
                       int32_t* d_srccount, int32_t* d_common, int32_t* d_status, hipStream_t s) {
@@ -1494,6 +1501,8 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
     for (int un : {2, 4})
         for (int il = 0; il < 2; ++il)
             PLAN_TRY(hipFuncSetAttribute(rows_kernel(il != 0, un), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowsLdsCap));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
+    PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
     PLAN_TRY(hipFuncSetAttribute((const void*)vet::k_spatial_u_lds<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_max));
@@ -1508,6 +1517,8 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
                     tk.push_back(transition_run_kernel<false>(upt, ex != 0, threads));
                     tk.push_back(transition_run_kernel<true>(upt, ex != 0, threads));
                 }
+        for (int upt : {1, 2, 4, 8})
+            for (int ex = 0; ex < 2; ++ex) tk.push_back(transition_batch_kernel(upt, ex != 0));
         for (const void* f : tk) PLAN_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
     }
     c->attrs_set = true;
@@ -1761,7 +1772,7 @@ static int batch_unweighted(vet_plan* pl, int n_videos, const vet_video* videos,
         const long rounds = (block + grid - 1) / grid;
         grid = (block + rounds - 1) / rounds;
         ProfScope ps(c, s, KID_SPATIAL);
-        const void* fn = pairs ? (const void*)vet::k_spatial_u_lds<false, true> : (const void*)vet::k_spatial_u_lds<false, false>;
+        const void* fn = pairs ? (const void*)vet::k_spatial_u_lds<false, true, true> : (const void*)vet::k_spatial_u_lds<false, false, true>;
         void* args[] = {(void*)&q};
         HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(THREADS), args, lds, s));
         HIP_TRY(hipGetLastError());
@@ -1999,7 +2010,7 @@ int vet_transition_entropy_batch(vet_plan* pl, int n_videos, const vet_video* vi
         const size_t n4 = ((size_t)L.n + 3) & ~(size_t)3;
         const size_t lds = 2 * 20 * 8 + 4 * n4 * 4 + (size_t)3 * HS * 4 + ((size_t)max_users + 2) * 8;
         ProfScope ps(c, s, KID_TRANSITION);
-        const void* fn = transition_run_kernel<false>(upt, exact, threads);
+        const void* fn = transition_batch_kernel(upt, exact);
         void* args[] = {(void*)&p};
         HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)wg), dim3(threads), args, lds, s));
         HIP_TRY(hipGetLastError());

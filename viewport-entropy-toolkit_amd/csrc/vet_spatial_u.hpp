@@ -137,7 +137,8 @@ __global__ void k_spatial_u(const SpatialParams p) {
 // ------------------------------------------------------------------------------------------
 // WEIGHTS: also write the per-frame tile counts (the analyzers' tile_weights).  PAIRS: 16-byte loads,
 // two users per lane (even U); otherwise one user per lane with 8-byte loads, any U.
-template <bool WEIGHTS, bool PAIRS>
+// BATCH: the launch covers a list of videos (p.videos); the single-video instantiation has none of that code
+template <bool WEIGHTS, bool PAIRS, bool BATCH = false>
 __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PPT = 2;
@@ -156,12 +157,12 @@ __global__ __launch_bounds__(1024, 8) void k_spatial_u_lds(const SpatialParams p
     // the video and frames of a block: the launch's only video, or one of a batch (vet_spatial_entropy_batch: block0 = the
     // video's first block, FPW = its frames per block; every video's U fits the launch's LDS tables)
     struct Blk { const double* mu; const double* mv; int U, ipf, nf; long f0; double* ent; int32_t* assign; int32_t* present; double* weights; float inv_ipf; };
-    const long nblocks = p.videos ? (long)p.n_blocks : ((long)p.T + FB - 1) / FB;
+    const long nblocks = BATCH ? (long)p.n_blocks : ((long)p.T + FB - 1) / FB;
     auto locate = [&](long blk) {
         Blk x;
         x.mu = p.src.mu; x.mv = p.src.mv; x.U = p.U; x.ent = p.ent_k; x.assign = p.assign; x.present = p.present; x.weights = p.weights;
         int T = p.T, fb = FB;
-        if (p.videos) {
+        if (BATCH) {
             int lo = 0, hi = p.n_videos - 1;                   // last video with block0 <= blk
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;

@@ -249,12 +249,12 @@ __device__ __forceinline__ int grid_dir_sel(double m, double v, int W, int H, bo
 
 // EXACT: U == UPT * blockDim, no bounds checks on the user index; THREADS: the workgroup size when it is a
 // compile-time constant (0: read blockDim)
-template <bool FROM_IDS, int UPT, bool EXACT, int THREADS>
+template <bool FROM_IDS, int UPT, bool EXACT, int THREADS, bool BATCH = false>
 __global__ void k_transition_run(const TransParams launch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TransParams p = launch;
     long b = blockIdx.x;
-    if (!FROM_IDS && launch.videos) {              // this workgroup's video of the batch
+    if (BATCH) {                                   // this workgroup's video of the batch
         int lo = 0, hi = launch.n_videos - 1;      // last video with wg0 <= blockIdx.x
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;

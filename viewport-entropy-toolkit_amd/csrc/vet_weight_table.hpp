@@ -102,7 +102,9 @@ __global__ void k_row_stats(const StatsParams p) {
             // row entropy -sum (w/S) log2(w/S) = log2 S - (sum w log2 w) / S; its own rounding error (~1e-15)
             // only matters where the bound is hopeless anyway
             const double H = k >= 2 ? fmax(log2(S) - L / S, 0.0) : 0.0;
-            const double base = H > 0.0 ? 36.5 * (double)k / (S * H) : __builtin_inf();
+            // entries are off by at most q/2 each — except a weight of exactly 1.0 at shift 0, whose mantissa 2^32
+            // saturates to 2^32 - 1 (k_wtab): that one entry is off by q, counted here as one more entry
+            const double base = H > 0.0 ? 36.5 * (double)(k + (mx >= 1.0 ? 1 : 0)) / (S * H) : __builtin_inf();
             worst_tab = fmax(worst_tab, base * ldexp(1.0, e - 33));
             worst_sweep = fmax(worst_sweep, base);
         }
