@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VET_VERSION 110 /* 0.1.1 */
+#define VET_VERSION 120 /* 0.1.2: + vet_transition_entropy_batch(_host); -0.0 keys in d_weights; NaN frames */
 #define VET_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy: the null stream with legacy ordering */
 
 enum {
