@@ -518,11 +518,6 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
 }
 
 bool any_binned(const vet_plan* pl);
-int rows_chunks(const vet::FusedLayout& lay) {         // 64-tile chunks of the largest lattice
-    int ch = 1;
-    for (int k = 0; k < lay.K; ++k) ch = std::max(ch, (lay.n[k] + 63) / 64);
-    return ch;
-}
 constexpr size_t kRowsLdsCap = 160 * 1024 - 512;      // k_spatial_rows: one workgroup per CU takes the whole LDS
 
 // Builds the plan's fused table (first use; synchronises).  state = -1: the plan stays on k_spatial_lut.

@@ -274,7 +274,6 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_spatial_rows(const RowsParams 
         // ---- W(i-1): row tasks from the queue; this wave's P at its own point of the queue
         bool p_done = !has_p;
         if (has_w || has_e) {
-            const uint32_t* set_r = set_b + (size_t)((i - 1) & 1) * FB * HS;
             uint32_t* set_wr = set_b + (size_t)((i - 1) & 1) * FB * HS;
             const uint32_t* list = list_b + (size_t)((i - 1) & 1) * FB * UCAP;
             unsigned long long* hist = hist_b + (size_t)((i - 1) & 1) * FB * N;
@@ -284,7 +283,6 @@ __global__ __launch_bounds__(ROWS_THREADS) void k_spatial_rows(const RowsParams 
                 for (int f = 0; f < nfw; ++f) nw_tasks += (ring_w[f] + RPT - 1) / RPT;
             const int ntasks = n_e + nw_tasks;                   // the queue: entropy chunks first, then row tasks
             const int my_point = n_e + (int)(((long)wv * nw_tasks * 3) / (4 * NW));
-            (void)set_r;
             for (;;) {
                 int c = 0;
                 if (lane == 0) c = atomicAdd(&ring_w[2 * FB], 1);
