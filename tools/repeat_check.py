@@ -1,5 +1,6 @@
-"""Race hunt: the integer formulations and the transition kernel are order independent by construction, so repeated
-calls on the same input must agree bit for bit.  Runs each case many times and compares with the first result."""
+"""Race hunt: the integer formulations and the transition kernel are order independent by construction and the FP
+table adds in a fixed order (round 3), so repeated calls on the same input must agree bit for bit.  Runs each case many
+times and compares with the first result.  Cases: (mode, users, frames, tile_counts, weighted, data, fov, power)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'viewport-entropy-toolkit_amd'))
@@ -14,9 +15,15 @@ cases = [("spatial", 1024, 3000, [500], True, "random_walk"), ("spatial", 1024, 
          ("spatial", 1024, 3000, [500], False, "random_walk"), ("spatial", 300, 500, [20, 50, 100, 250, 1000], True, "uniform"),
          ("transition", 512, 10000, [200], True, "random_walk"), ("transition", 512, 4000, [200], True, "clustered"),
          ("transition", 300, 999, [200], True, "uniform"), ("transition", 1500, 300, [50], True, "random_walk"),
-         ("transition", 5000, 40, [50, 20], True, "random_walk")]
+         ("transition", 5000, 40, [50, 20], True, "random_walk"),
+         # round 3: FP table (sorted rows, per-wave histograms), marker plans with the in-call resolver, fused + FP mixes
+         ("spatial", 1024, 2000, [500], True, "random_walk", 120.0, 20.0), ("spatial", 256, 2000, [500], True, "clustered", 10.0, 2.0),
+         ("spatial", 300, 1500, [50, 100], True, "random_walk", 120.0, 30.0), ("spatial", 100, 800, [50], True, "uniform", 120.0, 50.0),
+         ("spatial", 512, 1000, [500], True, "random_walk", 120.0, 150.0), ("spatial", 64, 600, [50, 500], True, "clustered", 60.0, 200.0)]
 t0 = time.perf_counter()
-for mode, U, T, tcs, weighted, kind in cases:
+for case in cases:
+    mode, U, T, tcs, weighted, kind = case[:6]
+    fov, power = (case[6], case[7]) if len(case) > 6 else (120.0, 2.0)
     mu_h, mv_h = bench.synth_video(U, T, 77, 0, kind)
     mu_h[::7, ::5] = np.nan; mv_h[::7, ::5] = np.nan
     mu_h[:, 0] = 0.5; mv_h[:, 0] = 0.5
@@ -25,7 +32,7 @@ for mode, U, T, tcs, weighted, kind in cases:
     ent = torch.empty(R, dtype=torch.float64, device=dev)
     idx = torch.empty((T, U) if mode == "spatial" else (R, U, 2), dtype=torch.int32, device=dev)
     st = torch.zeros(2, dtype=torch.int32, device=dev)
-    plan = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in tcs], 120.0, 2.0, weighted, 100, 200)
+    plan = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in tcs], fov, power, weighted, 100, 200)
     plan.set_table_policy(1)
     s = torch.cuda.Stream(device=dev)
     first = None
@@ -44,7 +51,8 @@ for mode, U, T, tcs, weighted, kind in cases:
         elif not (np.array_equal(got[0], first[0], equal_nan=True) and np.array_equal(got[1], first[1])):
             bad += 1
     form = plan.last_formulation(0) if mode == "spatial" and weighted else "-"
-    print(f"{mode:10s} U={U:5d} T={T:6d} tcs={tcs} weighted={weighted} {kind:11s} form={form:7s} repeats={reps} mismatches={bad}", flush=True)
+    print(f"{mode:10s} U={U:5d} T={T:6d} tcs={tcs} weighted={weighted} {kind:11s} fov={fov:g} power={power:g} form={form:7s} "
+          f"nan_frames={int(np.isnan(first[0]).sum())} repeats={reps} mismatches={bad}", flush=True)
     plan.close()
     assert bad == 0
 print(f"all cases bit-identical over {reps} repeats ({time.perf_counter() - t0:.0f} s)")
