@@ -16,7 +16,8 @@ calls = 0
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     tcs = [int(x) for x in rng.choice([3, 20, 50, 100, 200, 500], size=rng.integers(1, 4))]
     weighted = bool(rng.integers(0, 2))
-    plan = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in tcs], float(rng.choice([60, 120, 200])), 2.0, weighted, 100, 200)
+    power = float(rng.choice([2.0, 2.0, 20.0, 150.0]))        # round 3: FP tables and marker plans (in-call resolver) too
+    plan = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in tcs], float(rng.choice([60, 120, 200])), power, weighted, 100, 200)
     plan.set_table_policy(int(rng.integers(-1, 2)))
     for it in range(50):
         U, T = int(rng.integers(1, 300)), int(rng.integers(2, 400))
@@ -28,6 +29,11 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
         assert np.isfinite(r["entropy"]).all() or not weighted or True
         plan.transition(mu=mu, mv=mv)
         calls += 2
+        if it % 10 == 0:                                        # batched launches of every mode
+            vids = [(mu[: max(2, T // 2)], mv[: max(2, T // 2)]), (mu, mv), (mu[:, : max(1, U // 3)].copy(), mv[:, : max(1, U // 3)].copy())]
+            plan.spatial_batch(vids, want_assign=True, check=False)
+            plan.transition_batch(vids, want_pairs=True, check=False)
+            calls += 2
     plan.close()
 eng.synchronize()
 free1, _ = torch.cuda.mem_get_info()
