@@ -281,9 +281,15 @@ const void* spatial_w_kernel(int wmode, int R, bool precise = false) {
     return nullptr;
 }
 
+// fused rows are short (config 4: 94 entries = 2 blocks): four rows in flight per lane group and 7 workgroups per CU
+// (72 VGPRs, one spilled register) measured 3-5 % faster than two rows and 8 workgroups (config 4 0.165 -> 0.160 ms, 64 x config 2
+// 0.907 -> 0.882, defaults 0.531 -> 0.519); single-lattice tables keep two (profiles/r01/v3_*)
+#ifndef VET_FUSED_UN
+#define VET_FUSED_UN 4
+#endif
 template <bool FROM_IDS>
 const void* lut_kernel_fused(bool il, bool occ8, bool dedup) {
-#define VET_PICK(I, O, D) if (il == I && occ8 == O && dedup == D) return (const void*)vet::k_spatial_lut<FROM_IDS, 2, I, O, D, false, true>
+#define VET_PICK(I, O, D) if (il == I && occ8 == O && dedup == D) return (const void*)vet::k_spatial_lut<FROM_IDS, VET_FUSED_UN, I, O, D, false, true>
     VET_PICK(false, false, false); VET_PICK(false, true, false); VET_PICK(true, false, false); VET_PICK(true, true, false);
     VET_PICK(false, false, true); VET_PICK(false, true, true); VET_PICK(true, false, true); VET_PICK(true, true, true);
 #undef VET_PICK
@@ -731,9 +737,10 @@ int lut_frames_per_wg(int U, long total_frames, int n_cu, int n_sum) {
     // keep ~7 workgroups per CU resident: at most ~20 KB of LDS histograms per workgroup
     while (fpw > 1 && (size_t)fpw * n_sum * 8 > 20 * 1024) fpw /= 2;
     // the launch runs in waves of 8 workgroups per CU: fewer frames per workgroup where that shortens the tail
-    // (config 4: 2 500 workgroups of 4 frames = 2 waves x 4 frames; 10 000 of 1 frame = 5 x 1; measured 0.175 -> 0.163 ms)
+    // (config 4: 2 500 workgroups of 4 frames = 2 waves x 4 frames; 5 000 of 2 frames = 3 x 2; 10 000 of 1 frame = 5 x 1;
+    // measured 0.175 / 0.159 / 0.163 ms: the constant charges a workgroup's fixed cost)
     const long slots = 8L * n_cu;
-    auto cost = [&](int f) { const long wgs = (total_frames + f - 1) / f; return (double)((wgs + slots - 1) / slots) * (f + 0.35); };
+    auto cost = [&](int f) { const long wgs = (total_frames + f - 1) / f; return (double)((wgs + slots - 1) / slots) * (f + 0.6); };
     for (int f = fpw / 2; f >= 1; f /= 2)
         if (cost(f) < cost(fpw)) fpw = f;
     return fpw;
@@ -892,7 +899,7 @@ int launch_lut_fused(vet_plan* pl, const vet::SampleSrc& src, int U, int T, cons
     } else {
         q.FPW = 1; q.UC = 1;
     }
-    const bool occ8 = env_int("VET_LUT_OCC8", 0, 1, 1) != 0;
+    const bool occ8 = env_int("VET_LUT_OCC8", 0, 1, 0) != 0;
     DevBuf dbg;
     if (getenv("VET_LUT_DEBUG")) {           // development aid: cycles per stage (thread 0 of every workgroup), synchronous
         HIP_TRY(dbg.alloc(32));
