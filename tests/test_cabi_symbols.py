@@ -62,3 +62,24 @@ def test_product_does_not_import_the_oracle():
     for f in list(pkg.rglob("*.hip")) + list(pkg.rglob("*.hpp")) + list(pkg.rglob("Makefile")):
         code = re.sub(r"//.*|#.*", "", f.read_text())
         assert "oracle" not in code, f"{f} references the oracle"
+
+
+def test_one_hip_runtime_is_loaded():
+    """_native.load_library() preloads the HIP runtime the installed torch ships (same SONAME as the system one), so the
+    process ends up with exactly one libamdhip64 whatever is imported later ('One HIP runtime per process').
+    Checked in a child process: this one may have loaded things already."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, re\n"
+        f"sys.path.insert(0, {str(ROOT / 'viewport-entropy-toolkit_amd')!r})\n"
+        "from viewport_entropy_toolkit import _native\n"
+        "_native.load_library()\n"
+        "import torch\n"
+        "libs = sorted(set(re.findall(r'\\S*libamdhip64\\S*', open('/proc/self/maps').read())))\n"
+        "print(len(libs), _native.HIP_RUNTIME_PRELOADED in libs if _native.HIP_RUNTIME_PRELOADED else 'system')\n"
+    )
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1500:]
+    n, ok = out.stdout.split()[-2:]
+    assert n == "1" and ok in ("True", "system"), out.stdout
