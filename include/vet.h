@@ -155,6 +155,9 @@ int64_t vet_plan_n_dirs(const vet_plan *plan);
  * sweep (at <= 1024 users) formulations; inf = a frame exists whose entropy no fixed point resolves. */
 int vet_plan_set_table_policy(vet_plan *plan, int policy);
 int vet_plan_table_stride(const vet_plan *plan, int lattice);
+/* rows of a weight table = distinct directions up to the lattice's mirror symmetry (0 before the first table exists):
+ * a table takes (rows + 1) * stride * 6 bytes */
+int64_t vet_plan_table_rows(const vet_plan *plan);
 int vet_plan_last_formulation(const vet_plan *plan, int lattice);
 int vet_plan_error_bounds(vet_plan *plan, int lattice, double *table_bound, double *sweep_bound);
 /* Parity hooks: read back the device-built tables (synchronous). */

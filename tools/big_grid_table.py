@@ -15,8 +15,8 @@ res = plan.spatial(mu=mu, mv=mv)
 t2 = time.perf_counter()
 res2 = plan.spatial(mu=mu, mv=mv)
 t3 = time.perf_counter()
-print('plan %.1f ms, first call (table build, stride %d, %.1f GB) %.1f ms, second call %.2f ms' % (
-    (t1 - t0) * 1e3, plan.table_stride(0), plan.n_dirs * plan.table_stride(0) * 6 / 1e9, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
+print('plan %.1f ms, first call (table build: %d rows for %d directions, stride %d, %.1f GB) %.1f ms, second call %.2f ms' % (
+    (t1 - t0) * 1e3, plan.table_rows(), plan.n_dirs, plan.table_stride(0), (plan.table_rows() + 1) * plan.table_stride(0) * 6 / 1e9, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
 ent, assign, _ = vo.spatial_series(mu, mv, W, H, [500])
 assert np.array_equal(res['assign'], assign)
 np.testing.assert_allclose(res['entropy'], ent, rtol=1e-8)

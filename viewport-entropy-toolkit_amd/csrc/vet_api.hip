@@ -126,10 +126,12 @@ struct vet_plan {
     int weighted = 1;
     double cos_cull = 0.0;
     int table_policy = 0;          // 0 by call size, 1 table whenever it is inside the contract, -1 never
-    uint32_t* d_alias = nullptr;   // [n_dirs] direction id -> table row | mirrored << 31 (ensure_alias)
+    uint32_t* d_alias = nullptr;   // [n_dirs] direction id -> table row (dense) | mirrored << 31 (ensure_alias)
     bool mirror = false;           // rows are shared between mirror-image directions
     uint2* d_dirrec = nullptr;     // [n_dirs] alias | nearest tile | lattice-0 row meta (k_dirrec), dedup-capable plans
-    std::vector<uint32_t> h_alias; // host copy of d_alias
+    std::vector<uint32_t> h_alias; // direction id -> canonical DIRECTION | mirrored << 31 (host only)
+    int n_rows = 0;                // table rows in use = canonical directions, densely numbered (ensure_alias)
+    int* d_canon = nullptr;        // [n_rows] table row -> its direction
     // fused table of k_spatial_rows (vet_spatial_rows.hpp): one row per distinct direction over ALL lattices
     struct Fused {
         int state = 0;             // 0 not built, 1 ready, -1 not usable for this plan
@@ -369,14 +371,27 @@ int ensure_alias(vet_plan* pl) {
             if (!(a & 0x80000000u) && a != d) alias[d] = alias[a];
         }
     }
+    // table rows = canonical directions, densely numbered: a table holds n_rows + 1 rows instead of n_dirs + 1
+    // (100 x 200 grid: 9 951 of 20 301 — half the memory and half the build time; 3840 x 1920: 4.3 instead of 8.5 GB)
+    std::vector<int> canon;
+    std::vector<uint32_t> rowid(D, 0u), rowsel(D);
+    for (size_t d = 0; d < D; ++d)
+        if (alias[d] == (uint32_t)d) { rowid[d] = (uint32_t)canon.size(); canon.push_back((int)d); }
+    for (size_t d = 0; d < D; ++d) rowsel[d] = rowid[alias[d] & 0x7FFFFFFFu] | (alias[d] & 0x80000000u);
     uint32_t* d_alias = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_alias, D * sizeof(uint32_t)));
-    const hipError_t e = hipMemcpy(d_alias, alias.data(), D * sizeof(uint32_t), hipMemcpyHostToDevice);
+    int* d_canon = nullptr;
+    hipError_t e = hipMalloc((void**)&d_alias, D * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_canon, canon.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(d_alias, rowsel.data(), D * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_canon, canon.data(), canon.size() * sizeof(int), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        (void)hipFree(d_alias);
+        if (d_alias) (void)hipFree(d_alias);
+        if (d_canon) (void)hipFree(d_canon);
         return fail(VET_ERR_DEVICE, "alias table upload failed: %s", hipGetErrorString(e));
     }
     pl->d_alias = d_alias;
+    pl->d_canon = d_canon;
+    pl->n_rows = (int)canon.size();
     pl->h_alias = std::move(alias);
     return VET_OK;
 }
@@ -449,7 +464,9 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     struct FreeMax { int* p; ~FreeMax() { (void)hipFree(p); } } free_max{d_max};
     hipError_t e = hipMemsetAsync(d_max, 0, 2 * sizeof(int), s);
     vet::WtabParams p{};
-    p.dir_unit = pl->d_dir_unit; p.D = (long)pl->n_dirs;
+    const long R = pl->n_rows;                 // rows = canonical directions (ensure_alias)
+    p.dir_unit = pl->d_dir_unit; p.D = R;
+    p.canon = pl->d_canon; p.shift_by_dir = 1; p.nl = 0;
     p.tiles = L.d_tiles; p.n = L.n;
     p.cos_cull = pl->cos_cull;
     p.wc.max_ang = pl->max_ang; p.wc.inv_max = 1.0 / pl->max_ang; p.wc.power = pl->power; p.wc.shift = 0;
@@ -457,7 +474,7 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     L.fp_table = pl->ultra || !(L.crit_tab <= kContractMargin);
     p.stride = 0; p.w = nullptr; p.idx = nullptr; p.meta = nullptr; p.row_s = L.d_row_s; p.row_e = L.d_row_e; p.fp = L.fp_table ? 1 : 0;
     p.maxcount = d_max; p.markers = nullptr; p.gs_log2 = -1;
-    const int blocks = grid_for((long)pl->n_dirs * vet::WAVE, 256, c->n_cu * 2);
+    const int blocks = grid_for(R * vet::WAVE, 256, c->n_cu * 2);
     {
         ProfScope ps(c, s, KID_WTAB);
         hipLaunchKernelGGL(vet::k_wtab<false>, dim3(blocks), dim3(256), 0, s, p);
@@ -469,7 +486,7 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     int align = 64;      // rows start on 128-byte lines (u16 tile rows) / 256 bytes (u32 weight rows)
     align = (env_int("VET_STRIDE_ALIGN", 64, 1024, align) + 63) / 64 * 64;   // whole 64-entry blocks: the walk reads whole blocks
     int stride = ((longest > 0 ? longest : 1) + align - 1) / align * align;
-    const size_t rows = (size_t)pl->n_dirs + 1;   // one extra, all-zero row (index n_dirs) for the gather's idle lanes
+    const size_t rows = (size_t)R + 1;            // one extra, all-zero row (index n_rows) for the gather's idle lanes
     const size_t bytes = rows * stride * 6 + rows * 4;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = kMaxTableBytes;
@@ -508,7 +525,7 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
         hipLaunchKernelGGL(vet::k_wtab<true>, dim3(blocks), dim3(256), 0, s, p);
     }
     HIP_TRY(hipGetLastError());
-    if (k == 0 && (uint64_t)pl->n_dirs <= vet::DEDUP_MAX_DIRS) {
+    if (k == 0 && (uint64_t)pl->n_rows <= vet::DEDUP_MAX_DIRS) {
         if (!pl->d_dirrec) HIP_TRY(hipMalloc((void**)&pl->d_dirrec, (size_t)pl->n_dirs * sizeof(uint2)));
         hipLaunchKernelGGL(vet::k_dirrec, dim3(grid_for(pl->n_dirs, 256, c->n_cu)), dim3(256), 0, s, pl->d_alias,
                            L.d_nearest, L.d_tab_meta, (long)pl->n_dirs, pl->d_dirrec);
@@ -546,14 +563,8 @@ int ensure_fused(vet_plan* pl, hipStream_t s) {
     rc = ensure_alias(pl);
     if (rc) return rc;
     const size_t D = (size_t)pl->n_dirs;
-    // canonical rows, densely numbered
-    std::vector<int> canon;
-    std::vector<uint32_t> rowid(D, 0u), rowsel(D);
-    for (size_t d = 0; d < D; ++d)
-        if (pl->h_alias[d] == (uint32_t)d) { rowid[d] = (uint32_t)canon.size(); canon.push_back((int)d); }
-    const int R = (int)canon.size();
+    const int R = pl->n_rows;                  // canonical directions, densely numbered (ensure_alias)
     if (R == 0) return VET_OK;
-    for (size_t d = 0; d < D; ++d) rowsel[d] = rowid[pl->h_alias[d] & 0x7FFFFFFFu] | (pl->h_alias[d] & 0x80000000u);
     vet::FusedLayout& lay = F.lay;
     lay.K = K; lay.Hs = 0; lay.CF = 0;
     for (int k = 0; k < K; ++k) {
@@ -564,25 +575,22 @@ int ensure_fused(vet_plan* pl, hipStream_t s) {
     lay.totals = getenv("VET_ROWS") ? 1 : 0;      // k_spatial_rows (experimental) wants the total slots; same-address LDS atomics cost k_spatial_lut 12 %
     if (lay.N > 65535 || lay.N < 32) return VET_OK;
 
-    DevBuf rowsel_d, ptrs_d, delta_d, max_d;
-    HIP_TRY(rowsel_d.alloc(D * 4));
+    DevBuf ptrs_d, delta_d, max_d;
     HIP_TRY(ptrs_d.alloc(sizeof(void*) * vet::MAX_LATTICES));
     HIP_TRY(delta_d.alloc(sizeof(int) * vet::MAX_LATTICES));
     HIP_TRY(max_d.alloc(sizeof(int)));
-    HIP_TRY(hipMalloc((void**)&F.d_canon, (size_t)R * sizeof(int)));
+    F.d_canon = nullptr;                       // (the plan's own: pl->d_canon)
     HIP_TRY(hipMalloc((void**)&F.d_rec, D * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&F.d_row_s, (size_t)R + 1));
-    HIP_TRY(hipMemcpyAsync(F.d_canon, canon.data(), (size_t)R * sizeof(int), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(rowsel_d.p, rowsel.data(), D * 4, hipMemcpyHostToDevice, s));
     const uint8_t* ptrs[vet::MAX_LATTICES] = {};
     for (int k = 0; k < K; ++k) ptrs[k] = pl->lat[k].d_row_s;
     HIP_TRY(hipMemcpyAsync(ptrs_d.p, ptrs, sizeof(ptrs), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(delta_d.p, 0, sizeof(int) * vet::MAX_LATTICES, s));
     HIP_TRY(hipMemsetAsync(max_d.p, 0, sizeof(int), s));
     HIP_TRY(hipMemsetAsync(F.d_row_s + R, vet::TAB_X, 1, s));
-    hipLaunchKernelGGL(vet::k_rowrec, dim3(grid_for((long)D, 256, c->n_cu)), dim3(256), 0, s, (const uint32_t*)rowsel_d.p,
+    hipLaunchKernelGGL(vet::k_rowrec, dim3(grid_for((long)D, 256, c->n_cu)), dim3(256), 0, s, (const uint32_t*)pl->d_alias,
                        (const uint16_t*)pl->lat[0].d_nearest, (long)D, F.d_rec);
-    hipLaunchKernelGGL(vet::k_fuse_shifts, dim3(grid_for(R, 256, c->n_cu)), dim3(256), 0, s, (const int*)F.d_canon, R, K,
+    hipLaunchKernelGGL(vet::k_fuse_shifts, dim3(grid_for(R, 256, c->n_cu)), dim3(256), 0, s, (const int*)pl->d_canon, R, K,
                        (const uint8_t* const*)ptrs_d.p, F.d_row_s, (int*)delta_d.p);
     vet::WtabParams p{};
     p.dir_unit = pl->d_dir_unit; p.D = R;
@@ -591,7 +599,7 @@ int ensure_fused(vet_plan* pl, hipStream_t s) {
     p.wc.max_ang = pl->max_ang; p.wc.inv_max = 1.0 / pl->max_ang; p.wc.power = pl->power; p.wc.shift = 0;
     p.stride = 0; p.w = nullptr; p.idx = nullptr; p.meta = nullptr; p.row_s = F.d_row_s; p.row_e = nullptr; p.fp = 0;
     p.markers = nullptr; p.maxcount = (int*)max_d.p; p.gs_log2 = -1;
-    p.canon = F.d_canon; p.nl = K; p.Hs = lay.Hs; p.N = lay.N; p.totals = lay.totals; p.lens = nullptr;
+    p.canon = pl->d_canon; p.shift_by_dir = 0; p.nl = K; p.Hs = lay.Hs; p.N = lay.N; p.totals = lay.totals; p.lens = nullptr;
     for (int k = 0; k < 8; ++k) { p.tiles_v[k] = k < K ? pl->lat[k].d_tiles : nullptr; p.n_v[k] = k < K ? lay.n[k] : 0; p.off_v[k] = k < K ? lay.off[k] : 0; }
     const int blocks = grid_for((long)R * vet::WAVE, 256, c->n_cu * 2);
     {
@@ -615,7 +623,7 @@ int ensure_fused(vet_plan* pl, hipStream_t s) {
         sp.cos_cull = pl->cos_cull;
         sp.wc.max_ang = pl->max_ang; sp.wc.inv_max = 1.0 / pl->max_ang; sp.wc.power = pl->power; sp.wc.shift = 0;
         sp.row_s = nullptr; sp.row_e = nullptr; sp.crit = (unsigned long long*)crit.p;
-        sp.canon = F.d_canon; sp.shift_in = F.d_row_s;
+        sp.canon = pl->d_canon; sp.shift_in = F.d_row_s;
         hipLaunchKernelGGL(vet::k_row_stats, dim3(grid_for((long)R * vet::WAVE, 256, c->n_cu * 2)), dim3(256), 0, s, sp);
         unsigned long long bits = 0;
         HIP_TRY(hipMemcpyAsync(&bits, crit.p, 8, hipMemcpyDeviceToHost, s));
@@ -647,7 +655,7 @@ int ensure_fused(vet_plan* pl, hipStream_t s) {
         hipLaunchKernelGGL(vet::k_wtab<true>, dim3(blocks), dim3(256), 0, s, p);
     }
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(vet::k_dirrec, dim3(grid_for((long)D, 256, c->n_cu)), dim3(256), 0, s, (const uint32_t*)rowsel_d.p,
+    hipLaunchKernelGGL(vet::k_dirrec, dim3(grid_for((long)D, 256, c->n_cu)), dim3(256), 0, s, (const uint32_t*)pl->d_alias,
                        (const uint16_t*)pl->lat[0].d_nearest, (const uint32_t*)F.d_meta, (long)D, F.d_dirrec);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
@@ -821,7 +829,7 @@ int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& sr
         q.lat[k].stride = L.stride;
         q.lat[k].gs_log2 = L.gs_log2; q.lat[k].interleaved = L.interleaved ? 1 : 0;
         q.lat[k].n = L.n; q.lat[k].hmax = L.hmax;
-        q.lat[k].zrow = (uint32_t)pl->n_dirs;
+        q.lat[k].zrow = (uint32_t)pl->n_rows;
         q.n_sum += L.n;
         il = il || L.interleaved;
     }
@@ -830,13 +838,13 @@ int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& sr
     // the per-frame set of distinct rows pays for itself from ~128 users per frame on (measured: config 2, 64
     // users, 0.0332 ms without vs 0.0366 ms with; config 4, 256 users, equal; config 3, 1024 users, 1.60 -> 1.53 ms)
     const int dedup_users = env_int("VET_DEDUP_MIN_USERS", 1, 1 << 20, 128);
-    const bool dedup = (uint64_t)pl->n_dirs <= vet::DEDUP_MAX_DIRS && pl->d_dirrec && !getenv("VET_NO_DEDUP") &&
+    const bool dedup = (uint64_t)pl->n_rows <= vet::DEDUP_MAX_DIRS && pl->d_dirrec && !getenv("VET_NO_DEDUP") &&
                        (d_videos ? batch_max_users : U) >= dedup_users;
     int blocks = blocks_batch, threads = 256;
     size_t lds = lds_batch;
     bool occ8 = true;
     // FP table: canonical row order through a bitmap over (row, mirrored) where that is small (<= 8 KB of LDS)
-    q.sort_words = (fpt && dedup && 2 * pl->n_dirs <= 65536) ? (int)((2 * pl->n_dirs + 31) / 32) : 0;
+    q.sort_words = (fpt && dedup && 2 * pl->n_rows <= 65536) ? (int)((2 * pl->n_rows + 31) / 32) : 0;
     if (!d_videos) {
         q.UC = U < 2048 ? U : 2048;
         threads = fpt ? 256 : env_threads("VET_LUT_THREADS", threads);     // the FP table's row sort counts on 256 threads
@@ -1547,6 +1555,7 @@ int vet_plan_destroy(vet_plan* pl) {
         if (L.d_row_e) (void)hipFree(L.d_row_e);
     }
     if (pl->d_alias) (void)hipFree(pl->d_alias);
+    if (pl->d_canon) (void)hipFree(pl->d_canon);
     if (pl->d_dirrec) (void)hipFree(pl->d_dirrec);
     {
         auto& F = pl->fused;
@@ -1564,6 +1573,8 @@ int vet_plan_set_table_policy(vet_plan* pl, int policy) {
     pl->table_policy = policy > 0 ? 1 : (policy < 0 ? -1 : 0);
     return VET_OK;
 }
+
+int64_t vet_plan_table_rows(const vet_plan* pl) { return pl ? pl->n_rows : 0; }
 
 int vet_plan_table_stride(const vet_plan* pl, int k) {
     if (!pl || k < 0 || k >= (int)pl->lat.size()) return 0;
@@ -1869,7 +1880,7 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
     std::vector<vet::VideoDesc>& desc = c->batch_desc;
     size_t lds_max = 0;
     if (table) {
-        const bool dedup = (uint64_t)pl->n_dirs <= vet::DEDUP_MAX_DIRS && pl->d_dirrec && !getenv("VET_NO_DEDUP") &&
+        const bool dedup = (uint64_t)pl->n_rows <= vet::DEDUP_MAX_DIRS && pl->d_dirrec && !getenv("VET_NO_DEDUP") &&
                            max_users >= env_int("VET_DEDUP_MIN_USERS", 1, 1 << 20, 128);
         desc.resize(n_videos);
         int block = 0;
@@ -1879,7 +1890,7 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
             d.mu = x.d_mu; d.mv = x.d_mv; d.U = x.n_users; d.T = x.n_frames;
             d.entropy = x.d_entropy; d.assign = x.d_assign; d.present = x.d_present;
             const size_t lds = batch_video_geometry(c, d.U, total_frames, n_sum, dedup, &d.FPW, &d.UC, form0 == F_FTABLE ? 4 : 1,
-                                                    (form0 == F_FTABLE && dedup && 2 * pl->n_dirs <= 65536) ? (int)((2 * pl->n_dirs + 31) / 32) : 0);
+                                                    (form0 == F_FTABLE && dedup && 2 * pl->n_rows <= 65536) ? (int)((2 * pl->n_rows + 31) / 32) : 0);
             if (lds == 0) table = false;
             d.block0 = block; d.pad_ = 0;
             block += (d.T + d.FPW - 1) / d.FPW;

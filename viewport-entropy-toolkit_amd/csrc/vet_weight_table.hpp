@@ -133,10 +133,12 @@ struct WtabParams {
     const uint16_t* row_e;
     int fp;             // FP table: entries are FP32 weights scaled by 2^E of their row, meta field = E
     int* markers;       // FP table fill: number of marker entries written (in-FoV tiles without an FP32 value)
-    // fused table (vet_spatial_rows.hpp): row r belongs to direction canon[r] and runs over the nl lattices of the plan,
-    // an entry's tile index is its slot in the fused histogram; lens[r] = entries | shift << 11.  canon == null: the
-    // single-lattice table above (row = direction, slot = tile).
+    // Rows are densely numbered: row r belongs to the canonical direction canon[r] (null: row = direction); row_s / row_e
+    // are read per DIRECTION when shift_by_dir is set (k_row_stats of a lattice), per row otherwise (fused shifts).
+    // fused table (vet_spatial_lut.hpp, nl > 0): the row runs over the nl lattices of the plan and an entry's tile index is
+    // its slot in the fused histogram; lens[r] = entries | shift << 11.  nl == 0: one lattice (tiles, n), slot = tile.
     const int* canon;
+    int shift_by_dir;
     int nl;
     const double* tiles_v[8];
     int n_v[8], off_v[8];
@@ -175,18 +177,20 @@ __global__ void k_wtab(const WtabParams p) {
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
     int longest = 0, nmark = 0;
-    const int nl = p.canon ? p.nl : 1;
-    const int slots = p.canon ? p.N : p.n;                  // histogram slots the padding cycles through
+    const bool fused = p.nl > 0;
+    const int nl = fused ? p.nl : 1;
+    const int slots = fused ? p.N : p.n;                    // histogram slots the padding cycles through
     for (long d = wave; d < p.D; d += nwaves) {
         const long dd = p.canon ? (long)p.canon[d] : d;     // the row's direction
         const double dx = p.dir_unit[3 * dd], dy = p.dir_unit[3 * dd + 1], dz = p.dir_unit[3 * dd + 2];
         int count = 0;
-        const int row_shift = FILL ? (p.fp ? (int)p.row_e[d] : (int)p.row_s[d]) : 0;
+        const long si = p.shift_by_dir ? dd : d;
+        const int row_shift = FILL ? (p.fp ? (int)p.row_e[si] : (int)p.row_s[si]) : 0;
         const double scale = p.fp ? ldexp(1.0, row_shift) : ldexp(1.0, 32 + TAB_X - row_shift);        // 2^E / 2^(32 - e)
         unsigned long long rsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // fused rows: sum of the row's mantissas per lattice
         for (int l = 0; l < nl; ++l) {
-        const double* tiles = p.canon ? p.tiles_v[l] : p.tiles;
-        const int n = p.canon ? p.n_v[l] : p.n;
+        const double* tiles = fused ? p.tiles_v[l] : p.tiles;
+        const int n = fused ? p.n_v[l] : p.n;
         unsigned long long lsum = 0ull;
         for (int t0 = 0; t0 < n; t0 += WAVE) {
             const int t = t0 + lane;
@@ -215,7 +219,7 @@ __global__ void k_wtab(const WtabParams p) {
                 const int pos = count + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                 int slot = t;
-                if (p.canon) {                                  // fused_pos
+                if (fused) {                                    // fused_pos
                     const int h = n >> 1;
                     slot = t < h ? p.off_v[l] + t : (t >= n - h ? p.N - 1 - (p.off_v[l] + (n - 1 - t)) : 2 * p.nl + p.Hs + l);
                 }
@@ -224,9 +228,9 @@ __global__ void k_wtab(const WtabParams p) {
             }
             count += __popcll(mask);
         }
-        if (p.canon && FILL) rsum[l] = wave_sum(lsum);
+        if (fused && FILL) rsum[l] = wave_sum(lsum);
         }
-        if (p.canon && p.totals) {
+        if (fused && p.totals) {
             // two pseudo entries per lattice: high / low 32 bits of the lattice's mantissa sum -> total slots 2l, 2l+1
             // (vet_spatial_rows.hpp); a zero half is left out like any zero entry.  The count pass reserves all of them.
             unsigned w32 = 0u;

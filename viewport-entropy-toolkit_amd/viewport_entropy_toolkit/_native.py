@@ -88,6 +88,7 @@ SIGNATURES = {
     "vet_plan_n_dirs": (_I64, [_P]),
     "vet_plan_set_table_policy": (_I, [_P, _I]),
     "vet_plan_table_stride": (_I, [_P, _I]),
+    "vet_plan_table_rows": (_I64, [_P]),
     "vet_plan_last_formulation": (_I, [_P, _I]),
     "vet_plan_error_bounds": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_D)]),
     "vet_plan_read_dirs": (_I, [_P, _P]),
@@ -372,6 +373,10 @@ class Plan:
 
     def table_stride(self, lattice: int = 0) -> int:
         return int(self.lib.vet_plan_table_stride(self.handle, lattice))
+
+    def table_rows(self) -> int:
+        """Rows of the plan's weight tables: distinct directions up to the lattices' mirror symmetry (0 before a table exists)."""
+        return int(self.lib.vet_plan_table_rows(self.handle))
 
     def last_formulation(self, lattice: int = 0) -> str:
         """'table' | 'sweep' | 'precise' | 'ftable' of the last weighted call ('' before any)."""
