@@ -41,6 +41,13 @@ def _worker(rank, world, port, case, q):
             got = _dist.transition_frame_sharded(mu, mv, compute)
             if rank == 0:
                 q.put(("frames", bool(np.array_equal(got, compute(mu, mv)))))
+        elif case == "batched":
+            videos = [_synthetic.random_walk_video(5 + v, 12 + 2 * v, base_seed=3, video_id=v) for v in range(7)]
+            one = lambda mv_: vo.spatial_series(mv_[0], mv_[1], 100, 200, [20])[0]  # noqa: E731
+            got = _dist.analyze_videos_batched(videos, lambda vs: [one(v) for v in vs])
+            if rank == 0:
+                ok = set(got) == set(range(7)) and all(np.array_equal(got[v], one(videos[v])) for v in got)
+                q.put(("batched", ok))
         elif case == "sframes":
             mu, mv = _synthetic.random_walk_video(10, 41, base_seed=4, p_absent=0.1)
             compute = lambda a, b: vo.spatial_series(a, b, 100, 200, [20, 50])[0]  # noqa: E731
@@ -59,7 +66,8 @@ def _worker(rank, world, port, case, q):
 @pytest.mark.parametrize("case,world", [("videos", 2), ("frames", 2), ("fixed", 2),
                                         # uneven shards: 5 videos / 40 rows over 3 ranks, 8 ranks with more ranks than videos
                                         ("videos", 3), ("frames", 3), ("videos", 8), ("frames", 8),
-                                        ("sframes", 2), ("sframes", 3), ("sframes", 8)])
+                                        ("sframes", 2), ("sframes", 3), ("sframes", 8),
+                                        ("batched", 2), ("batched", 3), ("batched", 8)])
 def test_ranks_gloo(case, world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

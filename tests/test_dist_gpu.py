@@ -60,10 +60,15 @@ def _worker(rank, world, port, q):
         mu, mv = _synthetic.random_walk_video(40, 203, base_seed=8)
         trans = lambda a, b: plan.transition(mu=a, mv=b, want_pairs=False)["entropy"]             # noqa: E731
         cut = _dist.transition_frame_sharded(mu, mv, trans)
+        cut_s = _dist.spatial_frame_sharded(mu, mv, lambda a, b: plan.spatial(mu=a, mv=b, want_assign=False)["entropy"])
+        # every rank's share of the videos in ONE batched launch, one gather
+        got_b = _dist.analyze_videos_batched(videos, lambda vs: [r["entropy"] for r in plan.spatial_batch(vs)])
         if rank == 0:
             ok_v = set(got) == set(range(len(videos))) and all(np.array_equal(got[v], spatial(videos[v])) for v in got)
             ok_t = bool(np.array_equal(cut, trans(mu, mv)))
-            q.put((ok_v, ok_t))
+            ok_s = bool(np.array_equal(cut_s, plan.spatial(mu=mu, mv=mv, want_assign=False)["entropy"]))
+            ok_b = set(got_b) == set(range(len(videos))) and all(np.array_equal(got_b[v], spatial(videos[v])) for v in got_b)
+            q.put((ok_v, ok_t and ok_s and ok_b))
         plan.close()
     finally:
         dist.destroy_process_group()
@@ -82,7 +87,7 @@ def test_two_ranks_gloo_with_hip_compute():
         assert p.exitcode == 0
     ok_v, ok_t = q.get(timeout=10)
     assert ok_v, "videos sharded over two ranks differ from the one-process result"
-    assert ok_t, "frame-sharded transition entropy differs from the one-process result"
+    assert ok_t, "frame-sharded transition / spatial entropy or the batched video shares differ from the one-process result"
 
 
 def _rccl_worker(port, q):

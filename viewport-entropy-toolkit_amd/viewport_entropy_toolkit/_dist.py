@@ -106,6 +106,35 @@ def analyze_videos(videos: Sequence, compute: Callable[[object], np.ndarray], ds
     return results if rank == dst else None
 
 
+def analyze_videos_batched(videos: Sequence, compute_batch: Callable[[list], List[np.ndarray]], dst: int = 0, device=None):
+    """Many SHORT videos (the reference's scale-out unit, README.md:108-120): rank r takes videos r, r+W, r+2W, ... and
+    runs its whole share through ONE batched engine call (``compute_batch(list of videos) -> list of series``, e.g.
+    ``lambda vs: [r["entropy"] for r in plan.spatial_batch(vs)]`` — one launch instead of one per video), then ONE
+    gather brings every rank's series to ``dst``.  Returns {video index: series} on ``dst``."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    mine = video_shard(len(videos), rank, world)
+    series = [np.ascontiguousarray(s, dtype=np.float64).reshape(-1) for s in compute_batch([videos[v] for v in mine])] if mine else []
+    if len(series) != len(mine):
+        raise ValueError("compute_batch must return one series per video")
+    # one payload per rank: [number of videos, their lengths..., the series back to back]
+    payload = np.concatenate([[float(len(series))], [float(len(s)) for s in series]] + series) if series else np.zeros(1)
+    got = gather_series(payload, dst=dst, device=device)
+    if got is None:
+        return None
+    results = {}
+    for r, pay in enumerate(got):
+        n = int(pay[0])
+        lens = pay[1:1 + n].astype(np.int64)
+        off = 1 + n
+        for j, v in enumerate(video_shard(len(videos), r, world)[:n]):
+            results[v] = pay[off:off + lens[j]].copy()
+            off += int(lens[j])
+    return results
+
+
 def transition_frame_sharded(mu: np.ndarray, mv: np.ndarray, compute: Callable[[np.ndarray, np.ndarray], np.ndarray],
                              dst: int = 0, device=None):
     """One video across all ranks in transition mode: each rank computes a contiguous block of
