@@ -350,3 +350,24 @@ def test_transition_batch_in_one_launch(native, engine, tcs, shapes):
         assert np.array_equal(g["pairs"], pairs)
         np.testing.assert_allclose(g["entropy"], ent, rtol=1e-9, equal_nan=True)
     plan.close()
+
+
+@pytest.mark.parametrize("tcs,fov,power", [([50, 100], 120.0, 20.0), ([500], 10.0, 2.0), ([50], 120.0, 150.0), ([20, 50], 60.0, 200.0)])
+def test_batch_with_fp_tables_and_marker_plans(native, engine, tcs, fov, power):
+    """vet_spatial_entropy_batch on plans that take the FP table: one launch for plain FP tables (sorted rows, per-wave
+    histograms: bit-identical to the per-video calls), video by video where the table holds marker entries (their frames
+    go through the in-call resolver); NaN frames as the oracle has them."""
+    shapes = [(8, 30), (200, 40), (33, 7), (300, 12), (1, 5), (130, 25)]
+    vids = [video(u, t, seed=5 * i + u) for i, (u, t) in enumerate(shapes)]
+    plan = plan_for(native, engine, tcs, policy=1, fov=fov, power=power)
+    got = plan.spatial_batch(vids, want_assign=True, check=False)
+    assert plan.last_formulation(0) == "ftable"
+    for (mu, mv), g in zip(vids, got):
+        one = plan.spatial(mu=mu, mv=mv, check=False)
+        assert np.array_equal(g["entropy"], one["entropy"], equal_nan=True)
+        assert np.array_equal(g["assign"], one["assign"]) and np.array_equal(g["present"], one["present"])
+        ent, assign, _ = vo.spatial_series(mu, mv, 100, 200, tcs, fov_angle=fov, power_factor=power)
+        assert np.array_equal(np.isnan(g["entropy"]), np.isnan(ent))
+        ok = ~np.isnan(ent)
+        np.testing.assert_allclose(g["entropy"][ok], ent[ok], rtol=1e-6, atol=1e-15)
+    plan.close()
