@@ -371,3 +371,23 @@ def test_batch_with_fp_tables_and_marker_plans(native, engine, tcs, fov, power):
         ok = ~np.isnan(ent)
         np.testing.assert_allclose(g["entropy"][ok], ent[ok], rtol=1e-6, atol=1e-15)
     plan.close()
+
+
+@pytest.mark.parametrize("U,T,tcs,fov,power", [(3000, 7, [50], 120.0, 20.0), (2500, 5, [50, 100], 120.0, 30.0), (3000, 6, [500], 120.0, 150.0)])
+def test_fp_table_with_more_users_than_one_chunk(native, engine, U, T, tcs, fov, power):
+    """FP table on frames of more than 2048 users: the users arrive in several chunks (set and histograms side by side in
+    LDS, every chunk's row list rank-sorted), marker plans hand their undecided frames to the resolver, which walks the
+    users in chunks of 1024 too."""
+    mu, mv = video(U, T, seed=U + T)
+    plan = plan_for(native, engine, tcs, policy=1, fov=fov, power=power)
+    a = plan.spatial(mu=mu, mv=mv, want_weights=True, check=False)
+    assert plan.last_formulation(0) == "ftable"
+    b = plan.spatial(mu=mu, mv=mv, check=False)
+    assert np.array_equal(a["entropy"], b["entropy"], equal_nan=True)
+    ent, assign, weights = vo.spatial_series(mu, mv, 100, 200, tcs, fov_angle=fov, power_factor=power, want_weights=True)
+    assert np.array_equal(a["assign"], assign)
+    assert np.array_equal(np.isnan(a["entropy"]), np.isnan(ent))
+    ok = ~np.isnan(ent)
+    np.testing.assert_allclose(a["entropy"][ok], ent[ok], rtol=1e-6, atol=1e-15)
+    assert np.array_equal((a["weights"] != 0) | np.signbit(a["weights"]), (weights != 0) | np.signbit(weights))
+    plan.close()
