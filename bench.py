@@ -84,7 +84,7 @@ def kernel_src_sha():
     import hashlib
     h = hashlib.sha256()
     csrc = ROOT / "viewport-entropy-toolkit_amd" / "csrc"
-    for f in sorted(csrc.glob("*.hpp")) + [csrc / "vet_api.hip"]:
+    for f in sorted(csrc.glob("*.hpp")) + sorted(csrc.glob("*.hip")):
         h.update(f.read_bytes())
     return h.hexdigest()[:16]
 

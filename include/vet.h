@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VET_VERSION 120 /* 0.1.2: + vet_transition_entropy_batch(_host); -0.0 keys in d_weights; NaN frames */
+#define VET_VERSION 130 /* 0.1.3: + vet_angular_distances; every in-FoV tile is a key under every formulation */
 #define VET_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy: the null stream with legacy ordering */
 
 enum {
@@ -69,7 +69,7 @@ int vet_synchronize(vet_ctx *ctx);
 int vet_profile_enable(vet_ctx *ctx, int on);
 int vet_profile_reset(vet_ctx *ctx);
 /* kernel ids: 0 k_grid_dirs, 1 k_nearest_lut, 2 k_spatial (any variant), 3 k_transition,
- *             4 k_finalize, 5 k_wtab (direction weight table build) */
+ *             4 k_finalize, 5 k_wtab (direction weight table build), 6 k_rowids (sample -> row records) */
 int vet_profile_get(vet_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
 const char *vet_kernel_name(int kernel_id);
 
@@ -257,6 +257,15 @@ int vet_transition_entropy_host_resident(vet_plan *plan, const double *h_mu, con
 /* which: 0 = assignments / pairs, 1 = weights / source counts; rows [row0, row0 + n_rows) -> h_dst */
 int vet_result_fetch(vet_result *result, int which, int64_t row0, int64_t n_rows, void *h_dst);
 int vet_result_free(vet_result *result);
+
+/* ---- angular distances ------------------------------------------------------------------------
+ * vector_angle_distance / find_angular_distances (utilities/entropy_utils.py:41-87) for m vectors x n tile centres:
+ *   h_out[i*n + j] = arccos(clip(dot(v_i / |v_i|, t_j / |t_j|), -1, 1))   radians, [0, pi]
+ * h_vectors [m*3] and h_tiles [n*3] are raw (not normalised) xyz, as Vector holds them; a zero-length vector gives NaN
+ * (numpy's 0/0), no error.  Same arithmetic as the nearest-tile and weight kernels (find_nearest_tile is the first minimum
+ * of a row of this matrix).  Synchronous. */
+int vet_angular_distances(vet_ctx *ctx, const double *h_vectors, int64_t n_vectors, const double *h_tiles, int n_tiles,
+                          double *h_out);
 
 /* ---- tile boundary geometry of a Fibonacci tiling ---------------------------------------------
  * get_fb_tile_boundaries (utilities/data_utils.py:58-189): for every tile the boundary edges (pairs of points on

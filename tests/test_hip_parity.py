@@ -78,6 +78,97 @@ def test_nearest_lut_exhaustive_vs_reference(native, engine, golden_dir):
     plan.close()
 
 
+@pytest.mark.parametrize("W,H", [(640, 480)])
+def test_nearest_lut_exhaustive_off_the_default_grid(native, engine, W, H):
+    """Every one of the 308 321 directions of a 640 x 480 grid, tile_count 50 and 500: the engine's rule (arg-max of the
+    fused dot, then the first minimum among distance values that arccos maps together) against the oracle's
+    np.argmin(arccos(clip(dot))) (entropy_utils.py:61-64, 104)."""
+    plan = make_plan(native, engine, [50, 500], W, H)
+    dirs = vo.direction_grid(W, H).reshape(-1, 3)
+    for k, tc in enumerate((50, 500)):
+        near = plan.read_nearest(k)
+        ref = vo.nearest_tile(dirs, vo.fibonacci_lattice(tc))
+        assert np.array_equal(near, ref), f"tile_count {tc}: {(near != ref).sum()} of {len(ref)} directions differ"
+    plan.close()
+
+
+def test_angular_distances_vs_oracle(native, engine, golden_dir):
+    """vector_angle_distance / find_angular_distances (entropy_utils.py:41-87) through vet_angular_distances: the G7
+    directions x 501 / 51 tiles against the oracle.  Tolerance: the cosines agree to a few ulp (fused vs BLAS dot), and
+    d(arccos c) = dc / sin(d): |delta| <= 8 * 2^-52 / max(sin d, 1.5e-8) + 4 ulp of the distance itself."""
+    g = load(golden_dir, "g7_weight_rows.npz")
+    lon, lat = vo.axis_tables(100, 200)
+    dirs = vo.vector_from_spherical(lon[g["px"]], lat[g["py"]])
+    for tc in (500, 50, 2):
+        tiles = vo.fibonacci_lattice(tc)
+        got = engine.angular_distances(dirs, tiles)
+        ref = vo.angular_distances(dirs, tiles)
+        assert got.shape == ref.shape
+        bound = 8 * 2.0 ** -52 / np.maximum(np.sin(ref), 1.5e-8) + 4 * np.spacing(ref)
+        assert (np.abs(got - ref) <= bound).all(), float(np.max(np.abs(got - ref) / bound))
+        assert np.array_equal(np.argmin(got, axis=1), vo.nearest_tile(dirs, tiles))
+    # un-normalised inputs are re-normalised; identical vectors are at distance ~0, opposite ones at pi; 0-vector -> nan
+    v = np.array([[2.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.3, -0.4, 1.2]])
+    t = np.array([[5.0, 0.0, 0.0], [-0.1, 0.0, 0.0], [0.3, -0.4, 1.2]])
+    d = engine.angular_distances(v, t)
+    assert d[0, 0] == 0.0 and d[0, 1] == np.pi and np.isnan(d[1]).all() and d[2, 2] < 3e-8
+    np.testing.assert_allclose(d[[0, 2]], vo.angular_distances(v[[0, 2]], t), rtol=1e-14, atol=3e-8)
+
+
+def test_operator_level_distance_functions(native, engine):
+    """The callables the reference exports (utilities/__init__.py:30-31): same values, same shapes, same error type."""
+    from viewport_entropy_toolkit import Vector, ValidationError
+    from viewport_entropy_toolkit.utilities import vector_angle_distance, find_angular_distances, find_nearest_tile
+    tiles_xyz = vo.fibonacci_lattice(50)
+    tiles = [Vector(*row) for row in tiles_xyz]
+    v = Vector(0.3, -0.5, 0.81)
+    d = find_angular_distances(v, tiles)
+    assert d.shape == (51, 2) and np.array_equal(d[:, 0], np.arange(51.0))
+    ref = vo.angular_distances(np.array([[0.3, -0.5, 0.81]]), tiles_xyz)[0]
+    np.testing.assert_allclose(d[:, 1], ref, rtol=1e-14, atol=1e-15)
+    assert vector_angle_distance(v, tiles[7]) == d[7, 1]
+    assert isinstance(vector_angle_distance(v, tiles[7]), np.float64)
+    assert find_nearest_tile(v, tiles) == int(np.argmin(ref)) == int(d[np.argmin(d[:, 1])][0])
+    assert find_angular_distances(v, []).shape == (0,)
+    with pytest.raises(ValidationError, match="Error calculating vector angle"):
+        vector_angle_distance(v, (1.0, 2.0, 3.0))
+
+
+@pytest.mark.parametrize("policy", [pytest.param(-1, id="sweep"), pytest.param(0, id="by-size"), pytest.param(1, id="table")])
+@pytest.mark.parametrize("tc", [500, 50])
+def test_key_sets_exact_on_every_direction(native, engine, tc, policy):
+    """tile_weights holds EXACTLY the tiles with distance < fov/2 (entropy_utils.py:131-136) under every formulation:
+    all 20 301 directions as one-user frames, and two-user frames pairing the directions that carry a weight below
+    2^-33 of their row's scale (56 at tile_count 500, 2 at 50: the keys an integer table used to drop) with a
+    far-away partner."""
+    lon, lat = vo.axis_tables(100, 200)
+    py, px = np.divmod(np.arange(201 * 101), 101)
+    dirs = vo.vector_from_spherical(lon[px], lat[py])
+    tiles = vo.fibonacci_lattice(tc)
+    w, keys = vo.tile_weight_rows(dirs, tiles, return_keys=True)
+    assert np.array_equal(keys, w > 0)                      # power 2: nothing underflows
+    mu = ((px + 0.5) / 100.0)[:, None]
+    mv = ((py + 0.5) / 200.0)[:, None]
+    mu[px == 100] = 1.0
+    mv[py == 200] = 1.0
+    plan = make_plan(native, engine, [tc], policy=policy)
+    res = plan.spatial(mu=mu, mv=mv, want_weights=True)
+    got = (res["weights"] > 0) | np.signbit(res["weights"])
+    assert np.array_equal(got, keys), f"{(got != keys).any(axis=1).sum()} directions with a wrong key set"
+    # the named regression: rows with a key below 2^-33 of the row's largest weight
+    tiny = np.nonzero(((w > 0) & (w < w.max(axis=1, keepdims=True) * 2.0 ** -33)).any(axis=1))[0]
+    assert len(tiny) >= (50 if tc == 500 else 2)
+    partner = (tiny + 101 * 100 + 37) % len(dirs)
+    mu2 = np.stack([mu[tiny, 0], mu[partner, 0]], axis=1)
+    mv2 = np.stack([mv[tiny, 0], mv[partner, 0]], axis=1)
+    res2 = plan.spatial(mu=mu2, mv=mv2, want_weights=True)
+    got2 = (res2["weights"] > 0) | np.signbit(res2["weights"])
+    assert np.array_equal(got2, keys[tiny] | keys[partner])
+    ent = np.array([vo.spatial_entropy_frame(np.stack([dirs[a], dirs[b]]), tiles)[0] for a, b in zip(tiny, partner)])
+    np.testing.assert_allclose(res2["entropy"], ent, rtol=1e-6, atol=1e-15)
+    plan.close()
+
+
 def test_nearest_lut_large_grid_vs_oracle(native, engine):
     W, H = 3840, 1920
     plan = make_plan(native, engine, [50, 500], W, H)
@@ -196,9 +287,8 @@ def test_weight_rows_vs_reference(native, engine, golden_dir, policy):
         res = plan.spatial(mu=mu, mv=mv, want_weights=True)
         ref = g[f"{tag}__rows"]
         np.testing.assert_allclose(res["weights"], ref, rtol=1e-9, atol=1e-15 if policy < 0 else 2.0 ** -33)
-        if policy > 0:      # rows hold the tiles the reference's dict holds (down to 2^-33 of the row's largest weight)
-            assert not ((res["weights"] > 0) & ~(ref > 0)).any()
-            assert not ((ref >= 2.0 ** -33) & ~(res["weights"] > 0)).any()
+        # the row's keys are exactly the tiles of the reference's dict (entropy_utils.py:131-136), however small the weight
+        assert np.array_equal((res["weights"] > 0) | np.signbit(res["weights"]), ref > 0), (tag, policy)
         assert np.array_equal(res["assign"][:, 0], g[f"{tag}__nearest"])
         plan.close()
 

@@ -257,3 +257,40 @@ def test_lazy_result_column_over_a_row_provider(tmp_path):
     assert "tile_weights" in repr(df.head(2)) or True
     with pytest.raises(IndexError):
         DeviceRows(fake, 0, T)[T]
+
+
+# ---- error mapping of the transition analyzer (reference analyzers/transition_entropy.py:128-151) -------------
+def test_transition_empty_row_error_mapping():
+    """A frame whose dict is empty -> ValidationError("Empty vector dictionary") (utilities/entropy_utils.py:239-240);
+    both frames have users but nobody is in both -> the reference's division by the zero total (:322-327).  The FIRST
+    failing frame pair decides, as the reference's row loop would."""
+    from viewport_entropy_toolkit.analyzers.transition_entropy import TransitionEntropyAnalyzer as TA
+    nan = np.nan
+    # grid samples: frame 1 has nobody at all
+    mu = np.array([[0.1, 0.2], [nan, nan], [0.3, 0.4]])
+    e = TA._empty_row_error("grid", mu, mu.copy())
+    assert isinstance(e, vt.ValidationError) and str(e) == "Empty vector dictionary"
+    # both frames populated, disjoint users
+    mu = np.array([[0.1, nan], [nan, 0.2], [0.3, 0.4]])
+    assert isinstance(TA._empty_row_error("grid", mu, mu.copy()), ZeroDivisionError)
+    # the first failing pair decides: rows 0->1 disjoint (ZeroDivisionError) before the empty frame 2
+    mu = np.array([[0.1, nan], [nan, 0.2], [nan, nan]])
+    assert isinstance(TA._empty_row_error("grid", mu, mu.copy()), ZeroDivisionError)
+    # a sample absent in mv only counts as absent
+    mv = np.array([[0.1, 0.1], [nan, 0.1], [0.1, 0.1]])
+    mu = np.array([[0.1, nan], [0.1, nan], [0.1, 0.1]])
+    assert isinstance(TA._empty_row_error("grid", mu, mv), vt.ValidationError)
+    # hand-assigned frame tables arrive as direction ids (-1 absent)
+    ids = np.array([[0, -1], [-1, -1]], dtype=np.int32)
+    assert isinstance(TA._empty_row_error("ids", ids, None), vt.ValidationError)
+    ids = np.array([[0, -1], [-1, 3]], dtype=np.int32)
+    assert isinstance(TA._empty_row_error("ids", ids, None), ZeroDivisionError)
+
+
+def test_utilities_export_the_reference_names():
+    """Every entropy-path name the reference's utilities package exports (utilities/__init__.py:30-40) is importable."""
+    import viewport_entropy_toolkit.utilities as u
+    for name in ("vector_angle_distance", "find_angular_distances", "find_nearest_tile", "calculate_tile_weights",
+                 "compute_spatial_entropy", "compute_transition_entropy", "calculate_naive_tile_weights",
+                 "find_naive_tile_index", "compute_naive_spatial_entropy", "EntropyConfig"):
+        assert callable(getattr(u, name)) and name in u.__all__

@@ -18,7 +18,7 @@ DOMINANT = ("k_spatial_lut", "k_spatial_u_lds", "k_spatial_u", "k_spatial_w", "k
 def src_sha():
     h = hashlib.sha256()
     csrc = ROOT / "viewport-entropy-toolkit_amd" / "csrc"
-    for f in sorted(csrc.glob("*.hpp")) + [csrc / "vet_api.hip"]:
+    for f in sorted(csrc.glob("*.hpp")) + sorted(csrc.glob("*.hip")):
         h.update(f.read_bytes())
     return h.hexdigest()[:16]
 

@@ -2,13 +2,11 @@
 // Part of the gfx950 device code of the viewport -> tile -> entropy path (see vet_kernels.hpp for the map).
 // Reference citations are relative to /root/reference/src/viewport_entropy_toolkit/.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "vet_layout.hpp"
 #include <type_traits>
 
 namespace vet {
 
-constexpr int WAVE = 64;
 constexpr unsigned EMPTY_KEY = 0xFFFFFFFFu;
 
 // ------------------------------------------------------------------------------------------
@@ -31,6 +29,14 @@ __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
     return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+__device__ __forceinline__ int below(unsigned long long m) {      // set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
 // Workgroup barrier for LDS-only hand-offs: waits for this wave's LDS operations (lgkmcnt), not for

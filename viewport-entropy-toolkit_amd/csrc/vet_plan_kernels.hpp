@@ -1,4 +1,4 @@
-// vet_plan_kernels.hpp — per-plan tables (k_grid_dirs, k_unit_dirs, k_nearest_lut), k_log2_table, k_finalize
+// vet_plan_kernels.hpp — per-plan tables: k_grid_dirs, k_unit_dirs, k_nearest_lut, k_angular_distances
 // Part of the gfx950 device code of the viewport -> tile -> entropy path (see vet_kernels.hpp for the map).
 // Reference citations are relative to /root/reference/src/viewport_entropy_toolkit/.
 #pragma once
@@ -37,10 +37,18 @@ __global__ void k_unit_dirs(const double* __restrict__ raw, long D, double* __re
 }
 
 // ------------------------------------------------------------------------------------------
-// k_nearest_lut: find_nearest_tile (entropy_utils.py:89-106) for every direction of the table.
-// arccos is monotone, so arg-min distance == arg-max cosine; '>' keeps the lowest index on
-// exact ties, as np.argmin does.  lane = direction, the tile walks through LDS (broadcast).
+// k_nearest_lut: find_nearest_tile (entropy_utils.py:89-106) for every direction of the table:
+// np.argmin over arccos(clip(dot)) — the FIRST minimum, i.e. the lowest index among the tiles whose
+// distance VALUE is the smallest.  arccos is monotone, so the arg-max of the cosine ('>' keeps the
+// lowest index on exact ties) finds a tile of minimal distance; where the cosines of two tiles differ by
+// a few ulp, arccos may map them to one double, and the reference then keeps the lower index: the second
+// pass applies that rule literally to the (rare) tiles of lower index within 8 ulp of the best cosine.
+// lane = direction, the tiles walk through LDS (broadcast).
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double clip_unit(double c) {        // np.clip(c, -1, 1): NaN stays NaN
+    return c != c ? c : fmin(fmax(c, -1.0), 1.0);
+}
+
 __global__ void k_nearest_lut(const double* __restrict__ unit, long D, const double* __restrict__ tiles,
                               int n, uint16_t* __restrict__ nearest) {
     extern __shared__ double s_tiles[];
@@ -54,53 +62,32 @@ __global__ void k_nearest_lut(const double* __restrict__ unit, long D, const dou
             const double c = fma(z, s_tiles[3 * t + 2], fma(y, s_tiles[3 * t + 1], x * s_tiles[3 * t]));
             if (c > best) { best = c; bi = t; }
         }
+        const double near = best - 8.0 * 2.220446049250313e-16, dbest = acos(clip_unit(best));
+        for (int t = 0; t < bi; ++t) {
+            const double c = fma(z, s_tiles[3 * t + 2], fma(y, s_tiles[3 * t + 1], x * s_tiles[3 * t]));
+            if (c >= near && acos(clip_unit(c)) <= dbest) { bi = t; break; }
+        }
         nearest[d] = (uint16_t)bi;
     }
 }
 
-
-// log2(k) for k = 1..n-1 (entry 0 = 0): integer-count entropies look their logarithms up
-__global__ void k_log2_table(double* __restrict__ tab, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) tab[i] = i ? log2((double)i) : 0.0;
-}
-
 // ------------------------------------------------------------------------------------------
-// k_finalize: avg_entropy = (sum over lattices, in order) / K   (spatial_entropy.py:142-156)
+// k_angular_distances: vector_angle_distance / find_angular_distances (entropy_utils.py:41-87) for m
+// vectors x n tile centres: both vectors re-normalised (v / ||v||), dot, clip to [-1, 1], arccos.  The
+// arithmetic is the one k_nearest_lut and the weight kernels use (sqrt of the sum of squares, divisions,
+// a fused dot, ocml acos); a zero-length vector gives NaN as numpy's 0/0 does.  raw xyz in, radians out.
 // ------------------------------------------------------------------------------------------
-__global__ void k_finalize(const double* __restrict__ ent_k, int K, long rows, double* __restrict__ out) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < rows; i += (long)gridDim.x * blockDim.x) {
-        double s = 0.0;
-        for (int k = 0; k < K; ++k) s += ent_k[(long)k * rows + i];
-        out[i] = s / (double)K;
-    }
-}
-
-// the same for a batch of videos: per-lattice values in [K][rows] (the videos' frames back to back, video v's from
-// frame0[v]), the mean goes to every video's own output
-__global__ void k_finalize_batch(const double* __restrict__ ent_k, int K, long rows, const long* __restrict__ frame0,
-                                 double* const* __restrict__ outs, int n_videos) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < rows; i += (long)gridDim.x * blockDim.x) {
-        int lo = 0, hi = n_videos - 1;                         // last video with frame0 <= i
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (frame0[mid] <= i) lo = mid; else hi = mid - 1;
-        }
-        double s = 0.0;
-        for (int k = 0; k < K; ++k) s += ent_k[(long)k * rows + i];
-        outs[lo][i - frame0[lo]] = s / (double)K;
-    }
-}
-
-// the same for the frames of a resolve list only ([0] = count, then the frames)
-__global__ void k_finalize_list(const double* __restrict__ ent_k, int K, long rows, const uint32_t* __restrict__ list,
-                                double* __restrict__ out) {
-    const long n = (long)list[0];
-    for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < n; j += (long)gridDim.x * blockDim.x) {
-        const long i = (long)list[1 + j];
-        double s = 0.0;
-        for (int k = 0; k < K; ++k) s += ent_k[(long)k * rows + i];
-        out[i] = s / (double)K;
+__global__ void k_angular_distances(const double* __restrict__ vecs, long m, const double* __restrict__ tiles, int n,
+                                    double* __restrict__ out) {
+    const long total = m * (long)n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long v = i / n;
+        const int t = (int)(i - v * n);
+        const double vx = vecs[3 * v], vy = vecs[3 * v + 1], vz = vecs[3 * v + 2];
+        const double tx = tiles[3 * t], ty = tiles[3 * t + 1], tz = tiles[3 * t + 2];
+        const double lv = sqrt(vx * vx + vy * vy + vz * vz), lt = sqrt(tx * tx + ty * ty + tz * tz);
+        const double c = fma(vz / lv, tz / lt, fma(vy / lv, ty / lt, (vx / lv) * (tx / lt)));
+        out[i] = acos(clip_unit(c));
     }
 }
 

@@ -2,7 +2,11 @@
 // Part of the gfx950 device code of the viewport -> tile -> entropy path (see vet_kernels.hpp for the map).
 // Reference citations are relative to /root/reference/src/viewport_entropy_toolkit/.
 #pragma once
-#include "vet_weight_table.hpp"
+#include "vet_common.hpp"
+
+#ifndef VET_STAGE_CYCLES
+#define VET_STAGE_CYCLES 0
+#endif
 
 namespace vet {
 
@@ -13,40 +17,6 @@ namespace vet {
 // row; UN rows per group are in flight; rows are zero padded, so a group walks to the longest of
 // its UN rows only.
 // ------------------------------------------------------------------------------------------
-
-constexpr int MAX_LATTICES = 8;
-
-// ------------------------------------------------------------------------------------------
-// Fused histogram layout.  The plan's K lattices (analyzers/spatial_entropy.py:142-156 loops over
-// them per frame) share ONE histogram of N = Nr + 4K slots, Nr = 2 * (Hs + K), Hs = sum_k floor(n_k / 2):
-//     [ 2K total slots | first halves of lattices 0..K-1 | K centre slots | K mirrored centre slots |
-//       second halves, reversed | 2K mirrored total slots ]
-// laid out so that the ONE reflection pos -> N-1-pos maps every lattice onto itself the way the Fibonacci
-// lattice's mirror symmetry (x,y,z) -> (x,-y,-z) does (tile i <-> tile n_k-1-i, see ensure_alias): a direction
-// and its mirror image then share one fused table row, the mirrored one adding into N-1-pos.  The centre tile
-// of an odd lattice is its own mirror image; it owns two slots and the epilogue adds them.
-// Total slots: every table row ends with two pseudo entries per lattice — the high and low 32 bits of the sum
-// of the row's mantissas in that lattice — aimed at slots 2k / 2k+1, so the walk that builds the histogram also
-// builds its exact total (hi * 2^32 + lo) and the entropy pass needs no reduction of its own.
-// A distinct direction of a frame costs ONE row walk (one length word, one set-up) whatever K is, and the
-// short rows of small lattices share cache lines with the others (config 4, 51+101+201 tiles: 88 + 6 entries =
-// 5 lines instead of 3 rows x 3 lines + 2 meta words).
-// ------------------------------------------------------------------------------------------
-struct FusedLayout {
-    int K;
-    int n[MAX_LATTICES];        // tiles per lattice
-    int off[MAX_LATTICES];      // slot of tile 0 of lattice k = 2K + sum_{j<k} floor(n_j / 2)
-    int Hs, N;                  // N = 2 * (Hs + K) + 4K
-    int CF;                     // 64-tile chunks per frame = sum_k ceil(n_k / 64)
-    int totals;                 // the rows carry the pseudo entries of the total slots (else the epilogue sums the tiles)
-    double hmax[MAX_LATTICES];
-};
-__host__ __device__ __forceinline__ int fused_pos(const FusedLayout& L, int k, int i) {
-    const int h = L.n[k] >> 1;
-    if (i < h) return L.off[k] + i;
-    if (i >= L.n[k] - h) return L.N - 1 - (L.off[k] + (L.n[k] - 1 - i));
-    return 2 * L.K + L.Hs + k;
-}
 
 // wave-wide sums through DPP (row reductions + row broadcasts): the total in every lane, a fixed order
 #define VET_DPP(v, ctrl, rmask) __builtin_amdgcn_update_dpp(0, (v), (ctrl), (rmask), 0xF, true)
@@ -81,9 +51,6 @@ __device__ __forceinline__ unsigned long long wave_total(unsigned long long v) {
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), 63);
     return ((unsigned long long)hi << 32) | lo;
 }
-
-constexpr int ROW_BITS = 19;
-constexpr uint32_t ROW_MASK = (1u << ROW_BITS) - 1;
 
 // FPT: FP table — entries are FP32 weights (relative precision 2^-24 each: |dH|/H <= 1.2e-7 for every frame, whatever the
 // weights' dynamic range), scaled by 2^E of their row; the histogram is FP64 (ds_add_f64) in true units.
@@ -198,8 +165,6 @@ __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t*
 // entry * multiplicity into the frame histogram with ds_add_u64; a wave serves 64/GS rows at once and
 // two such steps are issued back to back to keep more loads in flight.
 // ------------------------------------------------------------------------------------------
-constexpr unsigned DEDUP_MAX_DIRS = (1u << 19) - 1;      // set key = row (19 bits) | mirror flag; slot = key << 12 | count
-
 struct LutLattice {
     const uint32_t* tab_w;
     const uint16_t* tab_i;
@@ -241,7 +206,7 @@ struct LutParams {
     int FPW, UC;
     int sort_words;               // FPT: words of the (row, mirrored) bitmap that orders a frame's distinct rows (0: rank sort)
     FusedLayout lay;              // FUSED: the launch's one "lattice" is the plan's fused table (n = lay.N slots)
-    unsigned long long* dbg;      // VET_LUT_DEBUG (FUSED): [4] cycles of thread 0 per stage, summed over the workgroups
+    unsigned long long* dbg;      // development builds (-DVET_STAGE_CYCLES=1): [4] cycles of thread 0 per stage, summed over the workgroups
     uint32_t* resolve;            // FP tables with marker entries: [0] = number of frames handed to the precise sweep
                                   // (a marked tile whose histogram stayed 0.0), then the frames; null otherwise
 };
@@ -321,10 +286,14 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const long f0 = blk * FPW;
     const int nf = (int)min((long)FPW, (long)T - f0);
-    unsigned long long tdbg[4] = {0, 0, 0, 0}, tlast = (FUSED && p.dbg) ? __builtin_readcyclecounter() : 0ull;
+#if VET_STAGE_CYCLES
+    unsigned long long tdbg[4] = {0, 0, 0, 0}, tlast = p.dbg ? __builtin_readcyclecounter() : 0ull;
     auto stage = [&](int i) {
-        if (FUSED && p.dbg) { const unsigned long long now = __builtin_readcyclecounter(); tdbg[i] += now - tlast; tlast = now; }
+        if (p.dbg) { const unsigned long long now = __builtin_readcyclecounter(); tdbg[i] += now - tlast; tlast = now; }
     };
+#else
+    auto stage = [](int) {};
+#endif
     if (!overlay)
         for (int i = tid; i < FPW * p.n_sum * PRIV; i += blockDim.x) hist[i] = 0ull;
     for (int i = tid; i < 2 * FPW; i += blockDim.x) cnt_chunk[i] = 0;
@@ -581,24 +550,21 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
     const double inv_unit = 1.0 / (4294967296.0 * (double)(1u << TAB_X));
     if (FUSED) {
         // exact total per lattice from the total slots; -sum p log2 p in a canonical order (64-tile chunks, a fixed
-        // reduction tree inside a chunk, chunks in order): bit-identical to k_spatial_rows on the same frame
+        // reduction tree inside a chunk, chunks in order): the same bits whatever the frames per workgroup
         const int N = p.lay.N, K = p.lay.K;
         for (int fl = wv; fl < nf; fl += NW) {
             const unsigned long long* hrow = hist + (size_t)fl * N;
             double total_entropy = 0.0;
             for (int k = 0; k < K; ++k) {
                 const int n = p.lay.n[k], hh = n >> 1;
-                unsigned long long hi = hrow[2 * k] + hrow[N - 1 - 2 * k], lo = hrow[2 * k + 1] + hrow[N - 2 - 2 * k];
-                if (!p.lay.totals) {
-                    hi = lo = 0ull;
-                    for (int t = lane; t < n; t += WAVE) {
-                        const int pos = fused_pos(p.lay, k, t);
-                        unsigned long long v = hrow[pos];
-                        if (t >= hh && t < n - hh) v += hrow[N - 1 - pos];
-                        hi += v >> 32; lo += v & 0xFFFFFFFFull;
-                    }
-                    hi = wave_total(hi); lo = wave_total(lo);
+                unsigned long long hi = 0ull, lo = 0ull;       // exact total: sums of the 32-bit halves
+                for (int t = lane; t < n; t += WAVE) {
+                    const int pos = fused_pos(p.lay, k, t);
+                    unsigned long long v = hrow[pos];
+                    if (t >= hh && t < n - hh) v += hrow[N - 1 - pos];
+                    hi += v >> 32; lo += v & 0xFFFFFFFFull;
                 }
+                hi = wave_total(hi); lo = wave_total(lo);
                 const double totd = (double)(hi + (lo >> 32)) * 4294967296.0 + (double)(lo & 0xFFFFFFFFull);
                 double hk = 0.0;
                 for (int t0 = 0; t0 < n; t0 += WAVE) {
@@ -678,11 +644,13 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
             if (present) present[f0 + fl] = np;
         }
     }
-    if (FUSED && p.dbg) {
+#if VET_STAGE_CYCLES
+    if (p.dbg) {
         stage(3);
         if (tid == 0)
             for (int i = 0; i < 4; ++i) atomicAdd(&p.dbg[i], tdbg[i]);
     }
+#endif
     if (p.status) {
         const unsigned long long anybad = __ballot(bad);
         if (anybad && lane == 0) atomicAdd(&p.status[0], (int)__popcll(anybad));

@@ -50,23 +50,6 @@ struct SpatialParams {
                                   // frames (any order); null = all T frames, blockIdx.x * FPW onwards
 };
 
-// the reference's FoV test and weight, evaluated as the reference does (entropy_utils.py:124-137).  True when
-// distance < max: the tile is then a key of the reference's dict WHATEVER the weight — a power factor large
-// enough makes (..) ** power underflow to exactly 0.0, the key stays (and 0 * log2 0 makes the frame NaN, :195-198).
-__device__ __forceinline__ bool fov_weight_cone(double c, const WeightCfg& w, double& wt) {
-    c = fmin(fmax(c, -1.0), 1.0);
-    const double d = acos(c);
-    wt = 0.0;
-    if (!(d < w.max_ang)) return false;
-    wt = pow((w.max_ang - d) / w.max_ang, w.power);
-    return true;
-}
-__device__ __forceinline__ double fov_weight_exact(double c, const WeightCfg& w) {
-    double wt;
-    (void)fov_weight_cone(c, w, wt);
-    return wt;
-}
-
 // "no key" marker of the FP64 histograms that keep the reference's key set: -0.0.  x + (+0.0) turns it into +0.0
 // (IEEE round to nearest), so a tile that only ever received weights of exactly 0.0 reads +0.0 = "key with the
 // value 0.0", and every positive weight adds as if the slot had held 0.

@@ -30,7 +30,14 @@ namespace vet {
 // k_wtab<false> finds the longest row (conservative cone test), k_wtab<true> fills the rows.
 // One wave per direction; lane = tile.
 // ------------------------------------------------------------------------------------------
-constexpr int TAB_X = 16;       // histogram unit 2^-(32+TAB_X): sums of < 2^16 weights <= 1 fit 64 bits
+// (TAB_X, the histogram unit 2^-(32+TAB_X), and MARKER_BITS live in vet_layout.hpp)
+//
+// Key sets.  Every tile with distance < max is a key of the reference's per-frame dict (entropy_utils.py:131-136), however
+// small its weight.  Integer tables therefore never store 0 for an in-FoV tile: a mantissa that rounds to 0 is stored as 1
+// (the entry is then off by less than q instead of q/2; k_row_stats counts such entries twice), so "histogram slot != 0"
+// is exactly "key of the reference's dict" and the epilogues need no key bitmap.  FP tables do the same with the smallest
+// FP32 subnormal where that cannot move any frame's entropy by 1e-7 relative (rows whose second largest weight is within
+// 2^-60 of the largest: FORCE_OK below) and keep a marker entry otherwise.
 
 // The reference's NaN frames (entropy_utils.py:131-135, 195-198).  Every tile with distance < max is a key of the
 // reference's per-frame dict, also when ((max - d) / max) ** power underflows to exactly 0.0; a key whose summed
@@ -41,7 +48,6 @@ constexpr int TAB_X = 16;       // histogram unit 2^-(32+TAB_X): sums of < 2^16 
 // the row's scale — as a MARKER entry (-0.0f: adds nothing), the walk records marker hits in a per-frame bitmap,
 // and a frame with a marked tile whose histogram stayed 0.0 is handed to the precise sweep (exact FP64 weights and
 // the exact key set), which decides NaN / not NaN as the reference does.
-constexpr uint32_t MARKER_BITS = 0x80000000u;            // -0.0f
 #define VET_ULTRA_TINY 0x1p-1048
 
 struct StatsParams {
@@ -52,7 +58,7 @@ struct StatsParams {
     double cos_cull;
     WeightCfg wc;
     uint8_t* row_s;             // [D+1] TAB_X + e per row (row D = the all-zero row)
-    uint16_t* row_e;            // [D+1] E = -(binary exponent of the row's largest weight), unclamped (FP table)
+    uint16_t* row_e;            // [D+1] E = -(binary exponent of the row's largest weight), unclamped (FP table), | ROW_E_FORCE_OK
     unsigned long long* crit;   // [3] bit patterns of non-negative doubles (atomicMax):
                                 //   [0] max_d 36.5 q_d k_d / (S_d H_d)   with the table's q_d = 2^(e_d - 33)
                                 //   [1] max_d 36.5 k_d / (S_d H_d)       (times the sweep's step, 2^(shift-53))
@@ -63,11 +69,11 @@ struct StatsParams {
     const uint8_t* shift_in;
 };
 
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
-    return v;
-}
+// row_e bit 15: the row's second largest weight is within 2^-60 of its largest.  Such a row has an entropy of at least
+// ~2^-70, against which an in-FoV weight below FP32 range, stored as the smallest subnormal (2^-149 of the row's scale),
+// moves no frame's entropy by more than 1e-30 relative (entropy is concave: a frame's entropy is at least the weighted
+// mean of its rows').  Rows without the flag keep such tiles as marker entries (resolved by the precise sweep).
+constexpr uint16_t ROW_E_FORCE_OK = 0x8000u;
 
 __global__ void k_row_stats(const StatsParams p) {
     const int lane = lane_id();
@@ -78,8 +84,8 @@ __global__ void k_row_stats(const StatsParams p) {
     for (long r = wave; r < p.D; r += nwaves) {
         const long d = p.canon ? (long)p.canon[r] : r;
         const double dx = p.dir_unit[3 * d], dy = p.dir_unit[3 * d + 1], dz = p.dir_unit[3 * d + 2];
-        double S = 0.0, L = 0.0, mx = 0.0;
-        int k = 0;
+        double S = 0.0, L = 0.0, mx = 0.0, mx2 = 0.0;      // mx2: second largest weight of the row
+        int k = 0, k33 = 0;
         for (int t0 = 0; t0 < p.n; t0 += WAVE) {
             const int t = t0 + lane;
             const bool valid = t < p.n;
@@ -88,13 +94,26 @@ __global__ void k_row_stats(const StatsParams p) {
             if (valid && c > p.cos_cull) {
                 double wt;
                 if (fov_weight_cone(c, p.wc, wt) && wt < VET_ULTRA_TINY) ++ultra;
-                if (wt > 0.0) { ++k; S += wt; L += wt * log2(wt); mx = fmax(mx, wt); }
+                if (wt > 0.0) {
+                    ++k; S += wt; L += wt * log2(wt);
+                    mx2 = fmax(mx2, fmin(mx, wt)); mx = fmax(mx, wt);
+                    // a mantissa that would round to 0 is stored as 1 (k_wtab): whatever the row's shift, that needs
+                    // wt < 2^-33; counted conservatively as one more entry each (off by < q instead of <= q/2)
+                    if (wt < 0x1p-33) ++k33;
+                }
             }
         }
-        k = wave_sum(k); S = wave_sum(S); L = wave_sum(L); mx = wave_max(mx);
+        k = wave_sum(k); k33 = wave_sum(k33); S = wave_sum(S); L = wave_sum(L);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {                  // top two of the wave
+            const double o1 = __shfl_xor(mx, o, WAVE), o2 = __shfl_xor(mx2, o, WAVE);
+            mx2 = fmax(fmin(mx, o1), fmax(mx2, o2));
+            mx = fmax(mx, o1);
+        }
         int e = 0;
         if (mx > 0.0) (void)frexp(mx, &e);                  // mx <= 2^e
-        if (lane == 0 && !p.canon) p.row_e[d] = (uint16_t)min(1000, max(0, -e));      // 2^E stays finite; weights below 2^-1048 are markers
+        if (lane == 0 && !p.canon)                          // 2^E stays finite; weights below 2^-1048 are markers
+            p.row_e[d] = (uint16_t)(min(1000, max(0, -e)) | (mx2 >= mx * 0x1p-60 && mx2 > 0.0 ? ROW_E_FORCE_OK : 0));
         e = min(0, max(-TAB_X, e));
         if (lane == 0 && !p.canon) p.row_s[d] = (uint8_t)(TAB_X + e);
         if (p.canon) e = (int)p.shift_in[r] - TAB_X;
@@ -104,7 +123,7 @@ __global__ void k_row_stats(const StatsParams p) {
             const double H = k >= 2 ? fmax(log2(S) - L / S, 0.0) : 0.0;
             // entries are off by at most q/2 each — except a weight of exactly 1.0 at shift 0, whose mantissa 2^32
             // saturates to 2^32 - 1 (k_wtab): that one entry is off by q, counted here as one more entry
-            const double base = H > 0.0 ? 36.5 * (double)(k + (mx >= 1.0 ? 1 : 0)) / (S * H) : __builtin_inf();
+            const double base = H > 0.0 ? 36.5 * (double)(k + k33 + (mx >= 1.0 ? 1 : 0)) / (S * H) : __builtin_inf();
             worst_tab = fmax(worst_tab, base * ldexp(1.0, e - 33));
             worst_sweep = fmax(worst_sweep, base);
         }
@@ -132,18 +151,17 @@ struct WtabParams {
     const uint8_t* row_s;
     const uint16_t* row_e;
     int fp;             // FP table: entries are FP32 weights scaled by 2^E of their row, meta field = E
-    int* markers;       // FP table fill: number of marker entries written (in-FoV tiles without an FP32 value)
+    int* markers;       // FP table fill: number of marker entries written (in-FoV tiles kept without a value)
     // Rows are densely numbered: row r belongs to the canonical direction canon[r] (null: row = direction); row_s / row_e
     // are read per DIRECTION when shift_by_dir is set (k_row_stats of a lattice), per row otherwise (fused shifts).
-    // fused table (vet_spatial_lut.hpp, nl > 0): the row runs over the nl lattices of the plan and an entry's tile index is
-    // its slot in the fused histogram; lens[r] = entries | shift << 11.  nl == 0: one lattice (tiles, n), slot = tile.
+    // fused table (vet_layout.hpp, nl > 0): the row runs over the nl lattices of the plan and an entry's tile index is
+    // its slot in the fused histogram.  nl == 0: one lattice (tiles, n), slot = tile.
     const int* canon;
     int shift_by_dir;
     int nl;
     const double* tiles_v[8];
     int n_v[8], off_v[8];
-    int Hs, N, totals;
-    uint16_t* lens;
+    int Hs, N;
     int* maxcount;
     int gs_log2;        // >= 0: well-filled blocks dealt over the 2^gs_log2 lanes of a gather group
 };
@@ -167,10 +185,6 @@ __device__ __forceinline__ bool block_interleaved(int len, int eb, int gs_log2) 
     const int B = 4 << gs_log2;
     return gs_log2 >= 0 && 4 * min(B, len - eb) >= 3 * B;
 }
-__device__ __forceinline__ int below(unsigned long long m) {      // set bits of m below this lane
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-}
-
 template <bool FILL>
 __global__ void k_wtab(const WtabParams p) {
     const int lane = lane_id();
@@ -185,13 +199,12 @@ __global__ void k_wtab(const WtabParams p) {
         const double dx = p.dir_unit[3 * dd], dy = p.dir_unit[3 * dd + 1], dz = p.dir_unit[3 * dd + 2];
         int count = 0;
         const long si = p.shift_by_dir ? dd : d;
-        const int row_shift = FILL ? (p.fp ? (int)p.row_e[si] : (int)p.row_s[si]) : 0;
+        const int row_shift = FILL ? (p.fp ? (int)(p.row_e[si] & 0x7FFFu) : (int)p.row_s[si]) : 0;
+        const bool force_ok = FILL && p.fp && (p.row_e[si] & ROW_E_FORCE_OK) != 0;
         const double scale = p.fp ? ldexp(1.0, row_shift) : ldexp(1.0, 32 + TAB_X - row_shift);        // 2^E / 2^(32 - e)
-        unsigned long long rsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // fused rows: sum of the row's mantissas per lattice
         for (int l = 0; l < nl; ++l) {
         const double* tiles = fused ? p.tiles_v[l] : p.tiles;
         const int n = fused ? p.n_v[l] : p.n;
-        unsigned long long lsum = 0ull;
         for (int t0 = 0; t0 < n; t0 += WAVE) {
             const int t = t0 + lane;
             const bool valid = t < n;
@@ -204,17 +217,23 @@ __global__ void k_wtab(const WtabParams p) {
                     double wt;
                     const bool in_fov = fov_weight_cone(c, p.wc, wt);
                     if (p.fp) {
-                        // ultra-tiny weights and FP32 underflows become markers: the key survives, the value adds nothing
+                        // every in-FoV tile stays a key.  No FP32 value (ultra-tiny weight, or underflow below the row's
+                        // scale): the smallest subnormal where that is harmless (FORCE_OK rows, not ultra-tiny), else a
+                        // marker — the key survives, the value adds nothing, the precise sweep decides the frame
                         w32 = wt < VET_ULTRA_TINY ? 0u : __float_as_uint((float)(wt * scale));
-                        if (in_fov && w32 == 0u) { w32 = MARKER_BITS; ++nmark; }
+                        if (in_fov && w32 == 0u) {
+                            if (force_ok && wt >= VET_ULTRA_TINY) w32 = 1u;
+                            else { w32 = MARKER_BITS; ++nmark; }
+                        }
                     } else {
+                        // integer mantissa, at least 1 for a tile in the FoV (the key set is the reference's)
                         w32 = (unsigned)fmin(rint(wt * scale), 4294967295.0);
+                        if (in_fov && w32 == 0u) w32 = 1u;
                     }
                 }
                 hit = w32 != 0u;
             }
             const unsigned long long mask = __ballot(hit);
-            if (FILL && hit) lsum += w32;
             if (FILL && hit) {
                 const int pos = count + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
@@ -228,21 +247,6 @@ __global__ void k_wtab(const WtabParams p) {
             }
             count += __popcll(mask);
         }
-        if (fused && FILL) rsum[l] = wave_sum(lsum);
-        }
-        if (fused && p.totals) {
-            // two pseudo entries per lattice: high / low 32 bits of the lattice's mantissa sum -> total slots 2l, 2l+1
-            // (vet_spatial_rows.hpp); a zero half is left out like any zero entry.  The count pass reserves all of them.
-            unsigned w32 = 0u;
-            if (FILL && lane < 2 * nl) w32 = (lane & 1) ? (unsigned)(rsum[lane >> 1] & 0xFFFFFFFFull) : (unsigned)(rsum[lane >> 1] >> 32);
-            const bool hit = FILL ? w32 != 0u : lane < 2 * nl;
-            const unsigned long long mask = __ballot(hit);
-            if (FILL && hit) {
-                const int pos = count + below(mask);
-                p.w[d * p.stride + pos] = w32;
-                p.idx[d * p.stride + pos] = (uint16_t)lane;
-            }
-            count += __popcll(mask);
         }
         if (FILL) {
             // padding: weight 0 on distinct tiles, so the gather can add every slot unconditionally
@@ -253,7 +257,6 @@ __global__ void k_wtab(const WtabParams p) {
             }
             if (lane == 0) {
                 if (p.meta) p.meta[d] = (uint32_t)count | ((uint32_t)row_shift << 16);
-                if (p.lens) p.lens[d] = (uint16_t)(count | (row_shift << 11));
             }
             // well-filled blocks of 16-lane rows: deal the entries by class (one wave pass per block, lane =
             // sorted entry; the loads of all lanes have returned before the first store issues)
@@ -322,7 +325,6 @@ __global__ void k_wtab(const WtabParams p) {
         }
         if (lane == 0) {
             if (p.meta) p.meta[p.D] = p.fp ? 0u : (uint32_t)TAB_X << 16;
-            if (p.lens) { p.lens[p.D] = (uint16_t)(TAB_X << 11); p.lens[p.D + 1] = 0; }
         }
     }
 }
@@ -339,15 +341,6 @@ __global__ void k_fuse_shifts(const int* __restrict__ canon, int R, int nl, cons
         out[r] = (uint8_t)s;
         for (int k = 0; k < nl; ++k)
             if (s > (int)row_s[k][d]) atomicMax(&delta[k], s - (int)row_s[k][d]);
-    }
-}
-
-// Per-direction record of k_spatial_rows (copied to LDS): fused row (15 bits) | mirrored << 15 | nearest tile << 16
-__global__ void k_rowrec(const uint32_t* __restrict__ rowsel, const uint16_t* __restrict__ nearest, long D,
-                         uint32_t* __restrict__ rec) {
-    for (long d = blockIdx.x * (long)blockDim.x + threadIdx.x; d < D; d += (long)gridDim.x * blockDim.x) {
-        const uint32_t a = rowsel[d];
-        rec[d] = (a & 0x7FFFu) | ((a >> 31) << 15) | ((uint32_t)nearest[d] << 16);
     }
 }
 

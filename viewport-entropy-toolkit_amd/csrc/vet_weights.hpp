@@ -51,18 +51,45 @@ __device__ __forceinline__ unsigned long long unit_to_fx(double w, int shift) {
     return (bits - 0x3FF0000000000000ull) >> shift;
 }
 
+// the reference's FoV test and weight, evaluated as the reference does (entropy_utils.py:124-137).  True when
+// distance < max: the tile is then a key of the reference's dict WHATEVER the weight — a power factor large
+// enough makes (..) ** power underflow to exactly 0.0, the key stays (and 0 * log2 0 makes the frame NaN, :195-198).
+__device__ __forceinline__ bool fov_weight_cone(double c, const WeightCfg& w, double& wt) {
+    c = fmin(fmax(c, -1.0), 1.0);
+    const double d = acos(c);
+    wt = 0.0;
+    if (!(d < w.max_ang)) return false;
+    wt = pow((w.max_ang - d) / w.max_ang, w.power);
+    return true;
+}
+__device__ __forceinline__ double fov_weight_exact(double c, const WeightCfg& w) {
+    double wt;
+    (void)fov_weight_cone(c, w, wt);
+    return wt;
+}
+
+// A tile with distance < max is a key of the reference's dict however small its weight (entropy_utils.py:131-136):
+// the fixed-point weight of an in-FoV tile is at least one unit (the truncation error stays below one unit, as the
+// error bound of the sweep assumes), so "histogram slot != 0" is exactly "key".  0 = outside the FoV.
 template <int WMODE>
 __device__ __forceinline__ unsigned long long fov_weight_fx(double c, const WeightCfg& w) {
+    double r;
     if (WMODE == 0) {
         c = fmin(fmax(c, -1.0), 1.0);
         const double d = acos(c);
         if (!(d < w.max_ang)) return 0ull;
-        const double r = (w.max_ang - d) / w.max_ang;
-        return unit_to_fx(pow(r, w.power), w.shift);
+        r = pow((w.max_ang - d) / w.max_ang, w.power);
     } else {
-        const double r = fmax((w.max_ang - fast_theta(c)) * w.inv_max, 0.0);   // 0 <=> not d < max
-        return unit_to_fx(WMODE == 1 ? r * r : r, w.shift);
+        r = (w.max_ang - fast_theta(c)) * w.inv_max;
+        if (r < 1e-9) {            // at the rim of the cone the reference's own test decides (rare: |d - max| < 1e-9 rad)
+            const double d = acos(fmin(fmax(c, -1.0), 1.0));
+            if (!(d < w.max_ang)) return 0ull;
+            r = (w.max_ang - d) / w.max_ang;
+        }
+        if (WMODE == 1) r = r * r;
     }
+    const unsigned long long fx = unit_to_fx(r, w.shift);
+    return fx ? fx : 1ull;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -22,7 +22,7 @@ LIB_PATH = Path(os.environ.get("VET_HIP_LIBRARY", _PKG_DIR.parent / "lib" / "lib
 
 VET_OK, VET_ERR_INVALID, VET_ERR_DEVICE, VET_ERR_RANGE, VET_ERR_EMPTY, VET_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 KERNEL_IDS = {"k_grid_dirs": 0, "k_nearest_lut": 1, "k_spatial": 2, "k_transition": 3, "k_finalize": 4,
-              "k_wtab": 5}
+              "k_wtab": 5, "k_rowids": 6}
 
 
 class NativeUnavailable(RuntimeError):
@@ -108,6 +108,7 @@ SIGNATURES = {
     "vet_result_fetch": (_I, [_P, _I, _I64, _I64, _P]),
     "vet_result_free": (_I, [_P]),
     "vet_fb_tile_boundaries": (_I, [_P, _P, _I, _I, _P, _P]),
+    "vet_angular_distances": (_I, [_P, _P, _I64, _P, _I, _P]),
     "vet_csv_read_tracks": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(Track), _I]),
     "vet_csv_free_tracks": (None, [_I, C.POINTER(Track)]),
 }
@@ -259,6 +260,15 @@ class Engine:
         return edges, count
 
     # --- profiling -------------------------------------------------------
+    def angular_distances(self, vectors: np.ndarray, tiles: np.ndarray) -> np.ndarray:
+        """[m, n] arccos(clip(dot(v/|v|, t/|t|))) — vector_angle_distance of the reference for every pair."""
+        vectors = np.ascontiguousarray(vectors, dtype=np.float64).reshape(-1, 3)
+        tiles = np.ascontiguousarray(tiles, dtype=np.float64).reshape(-1, 3)
+        out = np.empty((len(vectors), len(tiles)), dtype=np.float64)
+        if out.size:
+            _check(self.lib, self.lib.vet_angular_distances(self.handle, _ptr(vectors), len(vectors), _ptr(tiles), len(tiles), _ptr(out)))
+        return out
+
     def profile_enable(self, on: bool = True):
         _check(self.lib, self.lib.vet_profile_enable(self.handle, int(on)))
 

@@ -24,6 +24,19 @@ class TransitionEntropyAnalyzer(_EntropyAnalyzerBase):
 
     _logger = logger
 
+    @staticmethod
+    def _empty_row_error(kind, a, b) -> Exception:
+        """The exception the reference raises at the FIRST frame pair without a common user: a frame whose dict is
+        empty -> ValidationError("Empty vector dictionary") (utilities/entropy_utils.py:239-240); both frames have users
+        but nobody is in both -> the division by the zero total weight (:322-327)."""
+        import numpy as np
+        present = (a >= 0) if kind != "grid" else ~(np.isnan(a) | np.isnan(b))
+        common = (present[:-1] & present[1:]).any(axis=1)
+        r = int(np.argmin(common))                 # first row without a common user
+        if not present[r].any() or not present[r + 1].any():
+            return ValidationError("Empty vector dictionary")
+        return ZeroDivisionError("float division by zero")
+
     def compute_entropy(self) -> pd.DataFrame:
         kind, times, a, b, names = self._samples()
         t_start = time.perf_counter()
@@ -40,8 +53,7 @@ class TransitionEntropyAnalyzer(_EntropyAnalyzerBase):
             if e.code == _native.VET_ERR_RANGE:
                 raise ValidationError(str(e))
             if e.code == _native.VET_ERR_EMPTY:
-                # the reference divides by the (zero) number of common users
-                raise ZeroDivisionError("float division by zero")
+                raise self._empty_row_error(kind, a, b)
             raise
         self._record_compute(time.perf_counter() - t_start, a.size, len(res["entropy"]))
         tiles = self._fibonacci_vectors[self.config.tile_counts[0]]

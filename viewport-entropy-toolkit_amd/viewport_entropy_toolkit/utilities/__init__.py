@@ -14,7 +14,7 @@ _PUBLIC = {
             "find_nearest_point", "spherical_interpolation", "get_tile_corners", "triangulate_spherical_polygon",
             "angle_at_vertex", "calculate_spherical_triangle_area", "compute_spherical_polygon_area",
             "compute_fb_tile_areas", "compute_lat_lon_tile_areas"),
-    _entropy: ("EntropyConfig", "find_nearest_tile", "calculate_tile_weights", "compute_spatial_entropy",
+    _entropy: ("EntropyConfig", "vector_angle_distance", "find_angular_distances", "find_nearest_tile", "calculate_tile_weights", "compute_spatial_entropy",
                "compute_transition_entropy", "calculate_naive_tile_weights", "find_naive_tile_index",
                "compute_naive_spatial_entropy"),
     _viz: ("VisualizationConfig", "save_graph"),

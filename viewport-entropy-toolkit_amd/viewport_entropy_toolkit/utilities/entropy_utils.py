@@ -43,6 +43,29 @@ def _plan_for(vectors: List[Vector], tile_centers: List[Vector], config: Entropy
     return plan
 
 
+def vector_angle_distance(v1: Vector, v2: Vector) -> float:
+    """Angle between two vectors in radians: arccos(clip(dot(v1/|v1|, v2/|v2|), -1, 1)), on the HIP engine.
+
+    As in the reference, anything that goes wrong (a non-Vector argument, no device) surfaces as
+    ``ValidationError("Error calculating vector angle: ...")``; a zero-length vector gives nan."""
+    try:
+        pair = np.array([[v1.x, v1.y, v1.z], [v2.x, v2.y, v2.z]], dtype=np.float64)
+        return np.float64(_native.Engine.default().angular_distances(pair[:1], pair[1:])[0, 0])
+    except Exception as e:
+        raise ValidationError(f"Error calculating vector angle: {str(e)}")
+
+
+def find_angular_distances(vector: Vector, tile_centers: List[Vector]) -> np.ndarray:
+    """``[n, 2]`` array of ``[tile index, angular distance]`` rows (one kernel launch for the whole row)."""
+    if len(tile_centers) == 0:
+        return np.array([])
+    try:
+        d = _native.Engine.default().angular_distances(_xyz([vector]), _xyz(tile_centers))[0]
+    except Exception as e:
+        raise ValidationError(f"Error calculating vector angle: {str(e)}")
+    return np.column_stack([np.arange(len(tile_centers), dtype=np.float64), d])
+
+
 def find_nearest_tile(vector: Vector, tile_centers: List[Vector]) -> int:
     """Index of the tile centre at the smallest angular distance (lowest index on ties)."""
     plan = _plan_for([vector], tile_centers, EntropyConfig())
