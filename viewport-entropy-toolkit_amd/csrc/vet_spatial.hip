@@ -181,6 +181,7 @@ int launch_lut(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc& sr
     *launched = false;
     vet::LutParams q{};
     q.resolve = d_resolve;
+    q.dedup_min_users = c->tune.dedup_min_users;
     q.videos = d_videos; q.n_videos = n_videos;
     q.src = src; q.U = U; q.T = T;
     q.nearest = pl->lat[lat_idx[0]].d_nearest;
@@ -245,6 +246,7 @@ int launch_lut_fused(vet_plan* pl, const vet::SampleSrc& src, int U, int T, cons
     const auto& F = pl->fused;
     *launched = false;
     vet::LutParams q{};
+    q.dedup_min_users = c->tune.dedup_min_users;
     q.videos = d_videos; q.n_videos = n_videos;
     q.src = src; q.U = U; q.T = T;
     q.nearest = pl->lat[0].d_nearest; q.alias = nullptr; q.dirrec = F.d_dirrec; q.rec_meta = 1;

@@ -205,6 +205,8 @@ struct LutParams {
     int32_t* status;
     int FPW, UC;
     int sort_words;               // FPT: words of the (row, mirrored) bitmap that orders a frame's distinct rows (0: rank sort)
+    int dedup_min_users;          // DEDUP: videos of fewer users keep one row entry per user (as the launch without the set would:
+                                  // an FP table's sums then do not depend on which videos share a batch)
     FusedLayout lay;              // FUSED: the launch's one "lattice" is the plan's fused table (n = lay.N slots)
     unsigned long long* dbg;      // development builds (-DVET_STAGE_CYCLES=1): [4] cycles of thread 0 per stage, summed over the workgroups
     uint32_t* resolve;            // FP tables with marker entries: [0] = number of frames handed to the precise sweep
@@ -268,6 +270,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
         blk -= d.block0;
     }
     const int HS = DEDUP ? lut_hash_slots(UC) : 0;
+    const bool merge = DEDUP && U >= p.dedup_min_users;                          // equal rows of a frame share one entry
     const bool overlay = DEDUP && U <= UC;                                       // one chunk: set and histogram share space
     const int PRIV = FPT ? (int)(blockDim.x >> 6) : 1;                            // FP table: one histogram per wave
     const size_t hist_bytes = (size_t)FPW * p.n_sum * 8 * PRIV, hash_bytes = (size_t)FPW * HS * 4;
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
         const int uc = min(UC, U - u0);
         __syncthreads();
         for (int i = tid; i < FPW; i += blockDim.x) cnt_chunk[i] = 0;
-        if (DEDUP)
+        if (merge)
             for (int i = tid; i < FPW * HS; i += blockDim.x) hash[i] = EMPTY_KEY;
         __syncthreads();
         // SPT samples per thread and round: all sample loads first, then the table gathers, then the LDS set
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
                 const bool uniform = __ballot(fl != fl0) == 0ull;
                 bool won = false;
                 unsigned h = 0;
-                if (DEDUP) {
+                if (merge) {
                     if (valid) {
                         uint32_t* tab = hash + (size_t)fl * HS;
                         h = (row[k] * 2654435761u) >> hs_shift;
@@ -407,14 +410,14 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
                     base = __builtin_amdgcn_readfirstlane(base);
                     if (won) {
                         const size_t pos = (size_t)fl0 * UC + base + below(mw);
-                        rows[pos] = DEDUP ? h : row[k];
+                        rows[pos] = merge ? h : (DEDUP ? (row[k] << 12) | 1u : row[k]);
                         meta[pos] = m0[k];
                     }
                 } else {
                     if (valid) atomicAdd(&cnt_frame[fl], 1);
                     if (won) {
                         const size_t pos = (size_t)fl * UC + atomicAdd(&cnt_chunk[fl], 1);
-                        rows[pos] = DEDUP ? h : row[k];
+                        rows[pos] = merge ? h : (DEDUP ? (row[k] << 12) | 1u : row[k]);
                         meta[pos] = m0[k];
                     }
                 }
@@ -424,10 +427,11 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
         stage(0);
         if (DEDUP) {
             // slot numbers -> slot words (row << 12 | multiplicity)
-            for (int i = tid; i < nf * UC; i += blockDim.x) {
-                const int fl = i / UC, j = i - fl * UC;
-                if (j < cnt_chunk[fl]) rows[i] = hash[(size_t)fl * HS + rows[i]];
-            }
+            if (merge)
+                for (int i = tid; i < nf * UC; i += blockDim.x) {
+                    const int fl = i / UC, j = i - fl * UC;
+                    if (j < cnt_chunk[fl]) rows[i] = hash[(size_t)fl * HS + rows[i]];
+                }
             if (overlay && !FPT) {
                 __syncthreads();
                 for (int i = tid; i < FPW * p.n_sum; i += blockDim.x) hist[i] = 0ull;
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
             // ascending order, so that row j always goes to the same wave, lane group and turn of the walk below.
             __syncthreads();
             constexpr int EPT = 8;                               // UC <= 2048 rows over 256 threads
-            const bool by_bitmap = DEDUP && overlay && p.sort_words > 0;
+            const bool by_bitmap = merge && overlay && p.sort_words > 0;
             for (int fl = 0; fl < nf; ++fl) {
                 const int cnt = cnt_chunk[fl];
                 uint32_t* fr = rows + (size_t)fl * UC;
