@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--data", default="random_walk", choices=["random_walk", "uniform", "clustered", "single", "fixed", "uniform_half", "uniform_quarter"],
                     help="synthetic sample distribution (default: SURVEY §8d random walks)")
     ap.add_argument("--loop", action="store_true", help="batched workloads: one call per video instead of one launch")
+    ap.add_argument("--policy", type=int, default=0, choices=[-1, 0, 1],
+                    help="table policy of the plan (include/vet.h): 0 by call size (default), 1 table, -1 sweep")
     ap.add_argument("--shard", default="videos", choices=["videos", "frames"],
                     help="N > 1: one video per GPU (weak scaling, default) or ONE video cut along the frame "
                          "axis with a 1-frame halo in transition mode (strong scaling, BASELINE config 5)")
@@ -233,6 +235,8 @@ def main():
     plan = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in tcs], 120.0, 2.0, weighted, 100, 200)
     eng.synchronize()
     plan_ms = (time.perf_counter() - t0) * 1e3
+    if args.policy:
+        plan.set_table_policy(args.policy)
     # everything of a step — the engine's kernels, the copy into the gather buffer, the RCCL gather — is
     # enqueued on ONE explicit stream, so the gather is ordered after the kernel that produces its input
     run_stream = torch.cuda.Stream(device=dev)

@@ -69,7 +69,7 @@ int vet_synchronize(vet_ctx *ctx);
 int vet_profile_enable(vet_ctx *ctx, int on);
 int vet_profile_reset(vet_ctx *ctx);
 /* kernel ids: 0 k_grid_dirs, 1 k_nearest_lut, 2 k_spatial (any variant), 3 k_transition,
- *             4 k_finalize, 5 k_wtab (direction weight table build), 6 k_rowids (sample -> row records) */
+ *             4 k_finalize, 5 k_wtab (direction weight table build) */
 int vet_profile_get(vet_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
 const char *vet_kernel_name(int kernel_id);
 

@@ -391,3 +391,4 @@ def test_fp_table_with_more_users_than_one_chunk(native, engine, U, T, tcs, fov,
     np.testing.assert_allclose(a["entropy"][ok], ent[ok], rtol=1e-6, atol=1e-15)
     assert np.array_equal((a["weights"] != 0) | np.signbit(a["weights"]), (weights != 0) | np.signbit(weights))
     plan.close()
+

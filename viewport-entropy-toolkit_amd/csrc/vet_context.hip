@@ -14,7 +14,7 @@ namespace vh {
 namespace {
 thread_local std::string g_err;
 const char* const kKernelNames[KID_COUNT] = {"k_grid_dirs", "k_nearest_lut", "k_spatial", "k_transition",
-                                             "k_finalize", "k_wtab", "k_rowids"};
+                                             "k_finalize", "k_wtab"};
 
 // a value outside [lo, hi] (or not a number) is ignored
 int env_int(const char* name, int lo, int hi, int fallback) {
@@ -64,8 +64,6 @@ void Tuning::from_environment() {
     no_fused = env_flag("VET_NO_FUSED");
     fused_single = env_flag("VET_FUSED");
     lut_occ8 = env_int("VET_LUT_OCC8", 0, 1, 0);
-    no_rowids = env_flag("VET_NO_ROWIDS");
-    joint_frames = env_int("VET_JOINT_FRAMES", 1, 16, 0);
 }
 
 int collect_profile(vet_ctx* c) {

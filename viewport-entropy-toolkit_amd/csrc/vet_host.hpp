@@ -36,7 +36,7 @@ struct DevBuf {
     hipError_t alloc(size_t b) { return hipMalloc(&p, b ? b : 8); }
 };
 
-enum { KID_GRID = 0, KID_NEAREST = 1, KID_SPATIAL = 2, KID_TRANSITION = 3, KID_FINALIZE = 4, KID_WTAB = 5, KID_ROWIDS = 6, KID_COUNT = 7 };
+enum { KID_GRID = 0, KID_NEAREST = 1, KID_SPATIAL = 2, KID_TRANSITION = 3, KID_FINALIZE = 4, KID_WTAB = 5, KID_COUNT = 6 };
 
 struct EventPair {
     int kid;
@@ -65,8 +65,6 @@ struct Tuning {
     int no_fused = 0;           // VET_NO_FUSED
     int fused_single = 0;       // VET_FUSED: fused table also for one-lattice plans
     int lut_occ8 = 0;           // VET_LUT_OCC8
-    int no_rowids = 0;          // VET_NO_ROWIDS: keep the one-kernel form of the table formulation
-    int joint_frames = 0;       // VET_JOINT_FRAMES (0: by shape)
     void from_environment();
 };
 
@@ -84,7 +82,7 @@ struct vet_ctx {
     double* d_log2 = nullptr;      // log2(k), k = 0..4096
     bool attrs_set = false;        // dynamic-LDS limits of the run kernels raised (first plan)
     // grow-only device staging buffers (no hipMalloc per call): 0-6 host-buffer entry points, 7 batch descriptors,
-    // 8 transition scratch, 9 resolve list, 10 row records of the two-kernel table formulation
+    // 8 transition scratch, 9 resolve list
     void* pool[12] = {};
     size_t pool_cap[12] = {};
     // host copies of the last batch's descriptors: they must outlive the asynchronous copies that read them

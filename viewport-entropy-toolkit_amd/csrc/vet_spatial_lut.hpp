@@ -213,6 +213,102 @@ struct LutParams {
                                   // (a marked tile whose histogram stayed 0.0), then the frames; null otherwise
 };
 
+// ------------------------------------------------------------------------------------------
+// Entropy of integer (fixed-point) histograms — the epilogue of every integer table kernel (entropy_utils.py:194-211,
+// weighted mode: normaliser log2 n).  One pass per lattice: the exact total S (sums of the 32-bit halves) and
+// L = sum v log2 v together, then H = log2 S - L / S: one log2 per tile, one divide per lattice.  Against the
+// term-by-term form -sum (v/S) log2 (v/S) the cancellation costs ~60 ulp ABSOLUTE (2e-14); integer formulations only
+// run on plans whose every frame has an entropy above ~1e-3 (k_row_stats: the bound 36.5 q k / (2 S H) <= 1e-7 needs
+// it), i.e. <= 2e-11 relative.  Canonical order: 64-tile chunks, a fixed DPP tree inside a chunk, chunks in order ->
+// the same bits whatever the kernel, the frames per workgroup or the launch geometry.
+//   val(t): the histogram value of tile t of this lattice;  wrow: this frame's row of the weights output or null.
+// ------------------------------------------------------------------------------------------
+template <class V>
+__device__ __forceinline__ double lattice_entropy_int(int n, V val, double hmax, double* wrow, double inv_unit) {
+    const int lane = lane_id();
+    unsigned long long hi = 0ull, lo = 0ull;
+    double L = 0.0;
+    for (int t0 = 0; t0 < n; t0 += WAVE) {
+        const int t = t0 + lane;
+        double term = 0.0;
+        if (t < n) {
+            const unsigned long long v = val(t);
+            hi += v >> 32; lo += v & 0xFFFFFFFFull;
+            const double vd = (double)v;
+            if (v != 0ull) term = vd * log2(vd);
+            if (wrow) __builtin_nontemporal_store(vd * inv_unit, wrow + t);
+        }
+        L += wave_total(term);
+    }
+    hi = wave_total(hi); lo = wave_total(lo);
+    const double S = (double)(hi + (lo >> 32)) * 4294967296.0 + (double)(lo & 0xFFFFFFFFull);
+    if (!(S > 0.0)) return 0.0;                 // no tile in any user's FoV: the reference sums over an empty dict
+    return fmax(log2(S) - L / S, 0.0) / hmax;
+}
+
+// frames fl = wave, wave + NW, ... of the workgroup: K lattices laid end to end in a frame's histogram row
+__device__ __forceinline__ void lut_epilogue_int(const unsigned long long* hist, size_t frame_stride, int nf, long f0,
+                                                 int K, const int* n_of, const double* hmax_of, const int* np_of,
+                                                 double* entropy, int32_t* present, double* weights, int32_t* status) {
+    const int NW = blockDim.x >> 6, lane = lane_id(), wv = wave_id();
+    const double inv_unit = 1.0 / (4294967296.0 * (double)(1u << TAB_X));
+    for (int fl = wv; fl < nf; fl += NW) {
+        const unsigned long long* hrow = hist + (size_t)fl * frame_stride;
+        double total_entropy = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const int n = n_of[k];
+            total_entropy += lattice_entropy_int(n, [&](int t) { return hrow[t]; }, hmax_of[k],
+                                                 (k == 0 && weights) ? weights + (f0 + fl) * (long)n : nullptr, inv_unit);
+            hrow += n;
+        }
+        if (lane == 0) {
+            const int np = np_of[fl];
+            double e = total_entropy / (double)K;
+            if (np == 0) {
+                e = __builtin_nan("");
+                if (status) atomicAdd(&status[1], 1);
+            }
+            entropy[f0 + fl] = e;
+            if (present) present[f0 + fl] = np;
+        }
+    }
+}
+
+// the same over a fused histogram (vet_layout.hpp): lattice k's tile t sits in slot fused_pos(k, t); the centre tile of
+// an odd lattice owns two slots
+__device__ __forceinline__ void lut_epilogue_fused(const unsigned long long* hist, int nf, long f0, const FusedLayout& lay,
+                                                   const int* np_of, double* entropy, int32_t* present, double* weights,
+                                                   int32_t* status) {
+    const int NW = blockDim.x >> 6, lane = lane_id(), wv = wave_id();
+    const double inv_unit = 1.0 / (4294967296.0 * (double)(1u << TAB_X));
+    const int N = lay.N, K = lay.K;
+    for (int fl = wv; fl < nf; fl += NW) {
+        const unsigned long long* hrow = hist + (size_t)fl * N;
+        double total_entropy = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const int n = lay.n[k], hh = n >> 1;
+            auto val = [&](int t) {
+                const int pos = fused_pos(lay, k, t);
+                unsigned long long v = hrow[pos];
+                if (t >= hh && t < n - hh) v += hrow[N - 1 - pos];          // centre tile: both of its slots
+                return v;
+            };
+            total_entropy += lattice_entropy_int(n, val, lay.hmax[k], (k == 0 && weights) ? weights + (f0 + fl) * (long)n : nullptr,
+                                                 inv_unit);
+        }
+        if (lane == 0) {
+            const int np = np_of[fl];
+            double e = total_entropy / (double)K;
+            if (np == 0) {
+                e = __builtin_nan("");
+                if (status) atomicAdd(&status[1], 1);
+            }
+            entropy[f0 + fl] = e;
+            if (present) present[f0 + fl] = np;
+        }
+    }
+}
+
 // hash slots per frame: power of two >= 2 * UC, at least one wave's worth
 __host__ __device__ __forceinline__ int lut_hash_slots(int UC) {
     int hs = 64;
@@ -551,54 +647,13 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
     __syncthreads();
     stage(2);
     // entropy (entropy_utils.py:194-211, weighted: normaliser log2 n); wave w takes frames w, w+NW, ...
-    const double inv_unit = 1.0 / (4294967296.0 * (double)(1u << TAB_X));
     if (FUSED) {
-        // exact total per lattice from the total slots; -sum p log2 p in a canonical order (64-tile chunks, a fixed
-        // reduction tree inside a chunk, chunks in order): the same bits whatever the frames per workgroup
-        const int N = p.lay.N, K = p.lay.K;
-        for (int fl = wv; fl < nf; fl += NW) {
-            const unsigned long long* hrow = hist + (size_t)fl * N;
-            double total_entropy = 0.0;
-            for (int k = 0; k < K; ++k) {
-                const int n = p.lay.n[k], hh = n >> 1;
-                unsigned long long hi = 0ull, lo = 0ull;       // exact total: sums of the 32-bit halves
-                for (int t = lane; t < n; t += WAVE) {
-                    const int pos = fused_pos(p.lay, k, t);
-                    unsigned long long v = hrow[pos];
-                    if (t >= hh && t < n - hh) v += hrow[N - 1 - pos];
-                    hi += v >> 32; lo += v & 0xFFFFFFFFull;
-                }
-                hi = wave_total(hi); lo = wave_total(lo);
-                const double totd = (double)(hi + (lo >> 32)) * 4294967296.0 + (double)(lo & 0xFFFFFFFFull);
-                double hk = 0.0;
-                for (int t0 = 0; t0 < n; t0 += WAVE) {
-                    const int t = t0 + lane;
-                    double term = 0.0;
-                    if (t < n) {
-                        const int pos = fused_pos(p.lay, k, t);
-                        unsigned long long v = hrow[pos];
-                        if (t >= hh && t < n - hh) v += hrow[N - 1 - pos];          // centre tile: both of its slots
-                        if (v != 0ull) {
-                            const double qv = (double)v / totd;
-                            term = -(qv * log2(qv));
-                        }
-                        if (k == 0 && weights) __builtin_nontemporal_store((double)v * inv_unit, weights + (f0 + fl) * (long)n + t);
-                    }
-                    hk += wave_total(term);
-                }
-                total_entropy += hk / p.lay.hmax[k];
-            }
-            if (lane == 0) {
-                const int np = cnt_frame[fl];
-                double e = total_entropy / (double)K;
-                if (np == 0) {
-                    e = __builtin_nan("");
-                    if (p.status) atomicAdd(&p.status[1], 1);
-                }
-                entropy[f0 + fl] = e;
-                if (present) present[f0 + fl] = np;
-            }
-        }
+        lut_epilogue_fused(hist, nf, f0, p.lay, cnt_frame, entropy, present, weights, p.status);
+    } else if (!FPT) {
+        int n_of[MAX_LATTICES];
+        double hmax_of[MAX_LATTICES];
+        for (int k = 0; k < p.K; ++k) { n_of[k] = p.lat[k].n; hmax_of[k] = p.lat[k].hmax; }
+        lut_epilogue_int(hist, (size_t)p.n_sum, nf, f0, p.K, n_of, hmax_of, cnt_frame, entropy, present, weights, p.status);
     } else
     for (int fl = wv; fl < nf; fl += NW) {
         const unsigned long long* hrow = hist + (size_t)fl * PRIV * p.n_sum;
@@ -615,17 +670,17 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
             const int n = p.lat[k].n;
             // total weight can exceed 64 bits of fixed point: summed in FP64, fixed lane order + butterfly
             double totd = 0.0;
-            for (int t = lane; t < n; t += WAVE) totd += FPT ? fp_value(hrow, t) : (double)hrow[t];
+            for (int t = lane; t < n; t += WAVE) totd += fp_value(hrow, t);
             totd = wave_sum(totd);
             double h = 0.0;
             for (int t = lane; t < n; t += WAVE) {
-                const double v = FPT ? fp_value(hrow, t) : (double)hrow[t];
+                const double v = fp_value(hrow, t);
                 if (v != 0.0) {
                     const double q = v / totd;
                     h -= q * log2(q);
                 }
-                if (k == 0 && weights) __builtin_nontemporal_store(FPT ? v : v * inv_unit, weights + (f0 + fl) * (long)n + t);
-                if (FPT && marked && v == 0.0) {
+                if (k == 0 && weights) __builtin_nontemporal_store(v, weights + (f0 + fl) * (long)n + t);
+                if (marked && v == 0.0) {
                     const int bit = bit0 + t;
                     unresolved = unresolved || ((marked[(size_t)fl * MW + (bit >> 5)] >> (bit & 31)) & 1u) != 0u;
                 }
@@ -635,7 +690,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
             hrow += n;
             bit0 += n;
         }
-        if (FPT && marked && __ballot(unresolved) != 0ull && lane == 0)
+        if (marked && __ballot(unresolved) != 0ull && lane == 0)
             p.resolve[1 + atomicAdd(&p.resolve[0], 1u)] = (uint32_t)(f0 + fl);
         if (lane == 0) {
             const int np = cnt_frame[fl];
