@@ -227,6 +227,7 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     HIP_TRY(hipGetLastError());
     if (k == 0 && (uint64_t)pl->n_rows <= vet::DEDUP_MAX_DIRS) {
         if (!pl->d_dirrec) HIP_TRY(hipMalloc((void**)&pl->d_dirrec, (size_t)pl->n_dirs * sizeof(uint2)));
+        ProfScope ps(c, s, KID_WTAB);
         hipLaunchKernelGGL(vet::k_dirrec, dim3(grid_for(pl->n_dirs, 256, c->n_cu)), dim3(256), 0, s, pl->d_alias,
                            L.d_nearest, L.d_tab_meta, (long)pl->n_dirs, pl->d_dirrec);
         HIP_TRY(hipGetLastError());
@@ -359,8 +360,11 @@ int ensure_fused(vet_plan* pl, hipStream_t s) {
         hipLaunchKernelGGL(vet::k_wtab<true>, dim3(blocks), dim3(256), 0, s, p);
     }
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(vet::k_dirrec, dim3(grid_for((long)D, 256, c->n_cu)), dim3(256), 0, s, (const uint32_t*)pl->d_alias,
-                       (const uint16_t*)pl->lat[0].d_nearest, (const uint32_t*)F.d_meta, (long)D, F.d_dirrec);
+    {
+        ProfScope ps(c, s, KID_WTAB);
+        hipLaunchKernelGGL(vet::k_dirrec, dim3(grid_for((long)D, 256, c->n_cu)), dim3(256), 0, s, (const uint32_t*)pl->d_alias,
+                           (const uint16_t*)pl->lat[0].d_nearest, (const uint32_t*)F.d_meta, (long)D, F.d_dirrec);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     guard.armed = false;

@@ -52,6 +52,19 @@ __device__ __forceinline__ unsigned long long wave_total(unsigned long long v) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// base + (16-bit half of `pair`) * step as an LDS byte address (one VALU instruction); HIGH selects the upper half
+template <bool HIGH>
+__device__ __forceinline__ uint32_t lds_slot(uint32_t pair, int step, uint32_t base) {
+    uint32_t a;
+    if (HIGH) asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(a) : "v"(pair), "v"(step), "v"(base));
+    else asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(a) : "v"(pair), "v"(step), "v"(base));
+    return a;
+}
+__device__ __forceinline__ void lds_add_u64(uint32_t lds_byte_address, unsigned long long v) {
+    __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned long long*)(size_t)lds_byte_address, v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // FPT: FP table — entries are FP32 weights (relative precision 2^-24 each: |dH|/H <= 1.2e-7 for every frame, whatever the
 // weights' dynamic range), scaled by 2^E of their row; the histogram is FP64 (ds_add_f64) in true units.
 // marked / bit0: FP tables with marker entries (vet_weight_table.hpp) — bitmap of the frame's tiles (bit0 = the lattice's
@@ -137,10 +150,14 @@ __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t*
                     atomicAdd((double*)(hb[k] + (int)t[k].z * sgn[k]), (double)__uint_as_float(w[k].z) * scale[k]);
                     atomicAdd((double*)(hb[k] + (int)t[k].w * sgn[k]), (double)__uint_as_float(w[k].w) * scale[k]);
                 } else {
-                    atomicAdd((unsigned long long*)(hb[k] + (int)t[k].x * sgn[k]), (unsigned long long)w[k].x * mult[k]);
-                    atomicAdd((unsigned long long*)(hb[k] + (int)t[k].y * sgn[k]), (unsigned long long)w[k].y * mult[k]);
-                    atomicAdd((unsigned long long*)(hb[k] + (int)t[k].z * sgn[k]), (unsigned long long)w[k].z * mult[k]);
-                    atomicAdd((unsigned long long*)(hb[k] + (int)t[k].w * sgn[k]), (unsigned long long)w[k].w * mult[k]);
+                    // LDS byte address = base +- 8 * tile in ONE instruction: v_mad_i32_i16 reads the 16-bit tile straight out
+                    // of its half of the packed pair (op_sel), no extraction (histograms fit the LDS: fewer than 2^15 slots)
+                    const uint32_t hb32 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)hb[k];
+                    const uint2 tp = *(const uint2*)&t[k];
+                    lds_add_u64(lds_slot<false>(tp.x, sgn[k], hb32), (unsigned long long)w[k].x * mult[k]);
+                    lds_add_u64(lds_slot<true>(tp.x, sgn[k], hb32), (unsigned long long)w[k].y * mult[k]);
+                    lds_add_u64(lds_slot<false>(tp.y, sgn[k], hb32), (unsigned long long)w[k].z * mult[k]);
+                    lds_add_u64(lds_slot<true>(tp.y, sgn[k], hb32), (unsigned long long)w[k].w * mult[k]);
                 }
             }
         }
