@@ -16,7 +16,9 @@ Fixtures:
   G6 ingest edge cases, G7 per-direction weight rows, G8 dense transition
   frames (bucket quirk exercised), G9 operator-level edge cases, G10 naive lat/lon analyzer,
   G11 tile boundary / area geometry of the Fibonacci tiling,
-  G12 FoV weights that underflow to 0.0 (large power_factor): NaN pattern and the 0.0-valued tile_weights keys.
+  G12 FoV weights that underflow to 0.0 (large power_factor): NaN pattern and the 0.0-valued tile_weights keys,
+  G13 vector_angle_distance / find_angular_distances / find_nearest_tile values: G7's directions, un-normalised and
+      degenerate vectors, and a random sample of a 640 x 480 pixel grid (nearest tile off the default grid).
 """
 
 from __future__ import annotations
@@ -606,6 +608,48 @@ def g12_underflow(vt):
     np.savez_compressed(OUT / "g12_underflow.npz", **out)
 
 
+def g13_angular_distances(vt):
+    """entropy_utils.py:41-106 as the reference computes them: one np.dot / np.arccos per (vector, tile) pair."""
+    import warnings
+    from viewport_entropy_toolkit import Vector
+    from viewport_entropy_toolkit.utilities import (generate_fibonacci_lattice, vector_angle_distance,
+                                                    find_angular_distances, find_nearest_tile)
+    g2 = np.load(OUT / "g2_quantiser.npz")
+    g7 = np.load(OUT / "g7_weight_rows.npz")
+    grid = g2["vec_100x200"]
+    dirs = [Vector(*map(float, grid[py, px])) for px, py in zip(g7["px"], g7["py"])]
+    out = {"dirs": vec_arr(dirs)}
+    for tc in (500, 50, 2):
+        L = generate_fibonacci_lattice(tc)
+        d = np.stack([find_angular_distances(v, L) for v in dirs])          # [48, n, 2]
+        assert np.array_equal(d[:, :, 0], np.broadcast_to(np.arange(len(L), dtype=float), d.shape[:2]))
+        out[f"tc{tc}__dist"] = d[:, :, 1]
+        out[f"tc{tc}__nearest"] = np.array([find_nearest_tile(v, L) for v in dirs], dtype=np.int32)
+    # raw (not unit) vectors: identical / opposite / orthogonal / nearly parallel pairs (Vector itself refuses zero length)
+    a = np.array([[2.0, 0.0, 0.0], [0.3, -0.4, 1.2], [1e-8, 2e-8, -1e-8], [0.0, 1e-150, 0.0], [5.0, 5.0, 0.0], [-1.0, 1e-7, 0.0]])
+    b = np.array([[5.0, 0.0, 0.0], [-0.1, 0.0, 0.0], [0.3, -0.4, 1.2], [0.0, 3.0, 0.0], [1e3, -1e3, 1e-3], [1.0, 0.0, 0.0]])
+    pair = np.empty((len(a), len(b)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i, x in enumerate(a):
+            for j, y in enumerate(b):
+                pair[i, j] = vector_angle_distance(Vector(*x), Vector(*y))
+    out["raw_a"], out["raw_b"], out["raw_dist"] = a, b, pair
+    # off the default grid: 4 000 random pixels of a 640 x 480 video (+ the four corners and the centre)
+    lon, lat = _axis_tables(vt, 640, 480)
+    rng = np.random.default_rng(13)
+    px = np.concatenate([rng.integers(0, 641, 4000), [0, 640, 0, 640, 320]])
+    py = np.concatenate([rng.integers(0, 481, 4000), [0, 0, 480, 480, 240]])
+    vs = [Vector.from_spherical(float(lon[x]), float(lat[y])) for x, y in zip(px, py)]
+    out["big_px"], out["big_py"], out["big_vec"] = px, py, vec_arr(vs)
+    for tc in (50, 500):
+        L = generate_fibonacci_lattice(tc)
+        out[f"big_tc{tc}__nearest"] = np.array([find_nearest_tile(v, L) for v in vs], dtype=np.int32)
+    np.savez_compressed(OUT / "g13_angular.npz", **out)
+    print("G13 done")
+
+
+# ----------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -640,6 +684,8 @@ def main():
         g11_geometry(vt)
     if want("G12"):
         g12_underflow(vt)
+    if want("G13"):
+        g13_angular_distances(vt)
     if want("G4"):
         g4_spatial(vt, synth)
     if want("G5"):

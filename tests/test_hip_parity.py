@@ -115,6 +115,26 @@ def test_angular_distances_vs_oracle(native, engine, golden_dir):
     np.testing.assert_allclose(d[[0, 2]], vo.angular_distances(v[[0, 2]], t), rtol=1e-14, atol=3e-8)
 
 
+def test_angular_distances_vs_reference_golden(native, engine, golden_dir):
+    """G13, written by the live reference: distances of the G7 directions to 501 / 51 / 3 tile centres, raw (un-normalised,
+    nearly parallel, opposite) vector pairs, and find_nearest_tile on 4 005 pixels of a 640 x 480 grid."""
+    g = load(golden_dir, "g13_angular.npz")
+    for tc in (500, 50, 2):
+        ref = g[f"tc{tc}__dist"]
+        got = engine.angular_distances(g["dirs"], vo.fibonacci_lattice(tc))
+        bound = 8 * 2.0 ** -52 / np.maximum(np.sin(ref), 1.5e-8) + 4 * np.spacing(ref)
+        assert (np.abs(got - ref) <= bound).all(), float(np.max(np.abs(got - ref) / bound))
+        assert np.array_equal(np.argmin(got, axis=1), g[f"tc{tc}__nearest"])
+    np.testing.assert_allclose(engine.angular_distances(g["raw_a"], g["raw_b"]), g["raw_dist"], rtol=1e-14, atol=3e-8)
+    plan = make_plan(native, engine, [50, 500], 640, 480)
+    for k, tc in enumerate((50, 500)):
+        near = plan.read_nearest(k).reshape(481, 641)[g["big_py"], g["big_px"]]
+        assert np.array_equal(near, g[f"big_tc{tc}__nearest"]), tc
+    dirs = plan.read_dirs().reshape(481, 641, 3)[g["big_py"], g["big_px"]]
+    assert np.array_equal(dirs, g["big_vec"])
+    plan.close()
+
+
 def test_operator_level_distance_functions(native, engine):
     """The callables the reference exports (utilities/__init__.py:30-31): same values, same shapes, same error type."""
     from viewport_entropy_toolkit import Vector, ValidationError

@@ -229,3 +229,26 @@ def test_g12_underflowed_weights_give_nan(golden_dir, tc, fov, power):
         ok = g["px"][f] >= 0
         e, _, _ = vo.spatial_entropy_frame(grid[g["py"][f][ok], g["px"][f][ok]], L, float(fov), float(power))
         np.testing.assert_allclose(e, ref[f], rtol=RTOL, atol=1e-15, equal_nan=True)
+
+
+def test_g13_angular_distances_and_off_grid_nearest(golden_dir):
+    """vector_angle_distance / find_angular_distances / find_nearest_tile of the live reference (entropy_utils.py:41-106):
+    the oracle's batched restatement gives the same distances (the cosines may differ by an ulp or two between one
+    np.dot per pair and a matrix product: |delta| <= 8 * 2^-52 / sin d + 4 ulp) and the same nearest tiles, on the default
+    grid and on a 640 x 480 one."""
+    g = np.load(golden_dir / "g13_angular.npz")
+    for tc in (500, 50, 2):
+        tiles = vo.fibonacci_lattice(tc)
+        ref = g[f"tc{tc}__dist"]
+        got = vo.angular_distances(g["dirs"], tiles)
+        bound = 8 * 2.0 ** -52 / np.maximum(np.sin(ref), 1.5e-8) + 4 * np.spacing(ref)
+        assert (np.abs(got - ref) <= bound).all()
+        assert np.array_equal(vo.nearest_tile(g["dirs"], tiles), g[f"tc{tc}__nearest"])
+        assert np.array_equal(np.argmin(ref, axis=1), g[f"tc{tc}__nearest"])
+    got = vo.angular_distances(g["raw_a"], g["raw_b"])
+    np.testing.assert_allclose(got, g["raw_dist"], rtol=1e-14, atol=3e-8)
+    lon, lat = vo.axis_tables(640, 480)
+    vec = vo.vector_from_spherical(lon[g["big_px"]], lat[g["big_py"]])
+    assert np.array_equal(vec, g["big_vec"])
+    for tc in (50, 500):
+        assert np.array_equal(vo.nearest_tile(vec, vo.fibonacci_lattice(tc)), g[f"big_tc{tc}__nearest"])

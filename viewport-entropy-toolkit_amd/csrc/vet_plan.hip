@@ -352,6 +352,7 @@ int ensure_fused(vet_plan* pl, hipStream_t s) {
     }
     F.gs_log2 = 1;
     while (F.gs_log2 < 4 && (4 << F.gs_log2) < longest) ++F.gs_log2;
+    if (c->tune.gs_log2) F.gs_log2 = c->tune.gs_log2;
     F.interleaved = F.gs_log2 == 4 && 4 * longest >= 3 * 64 && c->tune.tab_interleave != 0;
     p.stride = stride; p.w = F.d_w; p.idx = F.d_i; p.meta = F.d_meta; p.maxcount = nullptr;
     p.gs_log2 = F.interleaved ? F.gs_log2 : -1;
