@@ -102,22 +102,57 @@ def test_transition_shapes(native, engine, U, T, tcs):
 
 
 def test_transition_global_hash_variant_on_small_frames(native, engine, monkeypatch):
-    """The any-number-of-users variant of k_transition (bucket hash in global scratch, persistent workgroups)
-    forced onto ordinary shapes: same results as the LDS variant, rows looped per workgroup."""
+    """The fallback of k_transition for lattices of thousands of tiles (bucket hash in global scratch, persistent
+    workgroups) forced onto ordinary shapes: same results as the LDS variant, rows looped per workgroup.  The tuning
+    environment is read when an engine is created: the forced variant runs on an engine of its own."""
     mu, mv = video(300, 700, seed=77, p_absent=0.1)
     mu[:, 0] = np.where(np.isnan(mu[:, 0]), 0.5, mu[:, 0])
     mv[:, 0] = np.where(np.isnan(mv[:, 0]), 0.5, mv[:, 0])
     plan = plan_for(native, engine, [50, 200])
     a = plan.transition(mu=mu, mv=mv, want_srccount=True)
+    plan.close()
     monkeypatch.setenv("VET_T_GLOBAL", "1")
-    b = plan.transition(mu=mu, mv=mv, want_srccount=True)
+    eng2 = native.Engine(0)
     monkeypatch.delenv("VET_T_GLOBAL")
+    plan = plan_for(native, eng2, [50, 200])
+    b = plan.transition(mu=mu, mv=mv, want_srccount=True)
+    plan.close()
+    eng2.close()
     for k in ("pairs", "srccount", "common"):
         assert np.array_equal(a[k], b[k]), k
-    np.testing.assert_allclose(b["entropy"], a["entropy"], rtol=1e-13, equal_nan=True)     # other workgroup size: other summation tree
+    np.testing.assert_allclose(b["entropy"], a["entropy"], rtol=1e-13, equal_nan=True)
     ent, pairs = vo.transition_series(mu, mv, 100, 200, [50, 200])
     assert np.array_equal(a["pairs"], pairs)
     np.testing.assert_allclose(a["entropy"], ent, rtol=1e-9, equal_nan=True)
+
+
+@pytest.mark.parametrize("U,T,tc,kind", [(9000, 4, 200, "walk"), (20000, 3, 200, "uniform"), (4097, 5, 20, "walk"),
+                                         (6000, 3, 1000, "uniform"), (5000, 4, 50, "crowd")])
+def test_transition_many_users_lds_ranges(native, engine, U, T, tc, kind):
+    """k_transition_big (more than 4 096 users: bucket hash in LDS, the row cut into ranges of source tiles): one pass
+    (random walk: few destinations per source tile), several passes (users scattered uniformly: every (source,
+    destination) pair its own bucket; 1001 tiles), crowded tiles (thousands of users on a handful of tiles: buckets with
+    thousands of users); against the literal dict walk of the reference."""
+    rng = np.random.default_rng(U + tc)
+    if kind == "walk":
+        mu, mv = video(U, T, seed=U + T, p_absent=0.05)
+    elif kind == "uniform":
+        mu = rng.random((T, U))
+        mv = np.clip(np.arccos(1.0 - 2.0 * rng.random((T, U))) / np.pi, 0.0, 1.0)
+        mu[rng.random((T, U)) < 0.05] = np.nan
+    else:
+        mu = rng.choice(np.array([0.1, 0.12, 0.5, 0.52, 0.9]), (T, U))
+        mv = rng.choice(np.array([0.3, 0.32, 0.7]), (T, U))
+    mu[:, 0] = np.where(np.isnan(mu[:, 0]), 0.5, mu[:, 0])
+    mv[:, 0] = np.where(np.isnan(mv[:, 0]), 0.5, mv[:, 0])
+    plan = plan_for(native, engine, [tc])
+    res = plan.transition(mu=mu, mv=mv, want_srccount=True)
+    ent, pairs = vo.transition_series(mu, mv, 100, 200, [tc], closed_form=False)
+    assert np.array_equal(res["pairs"], pairs)
+    n = 2 * (tc // 2) + 1
+    src = np.stack([np.bincount(pairs[r][pairs[r][:, 0] >= 0, 0], minlength=n) for r in range(T - 1)])
+    assert np.array_equal(res["srccount"], src)
+    np.testing.assert_allclose(res["entropy"], ent, rtol=1e-9, equal_nan=True)
     plan.close()
 
 

@@ -1,5 +1,6 @@
-"""k_transition_any (more users than the LDS kernel holds: bucket hash and per-user words in global scratch) at
-9 000 and 20 000 users, 200 tiles: kernel time and algorithmic GB/s (24 B per sample + 8 B per row).
+"""Transition mode beyond 4 096 users (k_transition_big: bucket hash in LDS, the row cut into ranges of source tiles; round 3:
+k_transition_any with the hash in global scratch) at 9 000 and 20 000 users, 200 tiles: kernel time and algorithmic GB/s
+(24 B per sample + 8 B per row).
 usage: python tools/transition_any_timing.py    (under rocprofv3 --kernel-trace --stats for the committed summary)"""
 import os
 import sys
@@ -12,7 +13,7 @@ import bench
 dev = torch.device('cuda', 0)
 eng = _native.Engine(0)
 plan = _native.Plan(eng, [_quantiser.lattice_xyz(200)], 120.0, 2.0, True, 100, 200)
-for U, T in ((4096, 513), (9000, 513), (20000, 257)):
+for U, T in ((4096, 513), (9000, 513), (20000, 257), (9000, 2049), (20000, 1025)):
     mu_h, mv_h = bench.synth_video(U, T, 1234, 0)
     mu = torch.from_numpy(mu_h).to(dev); mv = torch.from_numpy(mv_h).to(dev)
     ent = torch.empty(T, dtype=torch.float64, device=dev); idx = torch.empty((T, U, 2), dtype=torch.int32, device=dev)
@@ -34,4 +35,4 @@ for U, T in ((4096, 513), (9000, 513), (20000, 257)):
     alg = 24.0 * U * (T - 1) + 8.0 * (T - 1)
     print(f"U={U:6d} rows={T - 1:4d} kernel {ms / n:8.3f} ms  {U * (T - 1) / (ms / n * 1e-3):.3e} pair-samples/s  "
           f"{alg / (ms / n * 1e-3) / 1e9:7.1f} GB/s algorithmic ({alg / (ms / n * 1e-3) / 8e12:.3f} of 8 TB/s)"
-          f"  kernel={'k_transition_run (LDS)' if U <= 4096 else 'k_transition_any (global scratch)'}", flush=True)
+          f"  kernel={'k_transition_run (registers + LDS)' if U <= 4096 else 'k_transition_big (LDS hash, source-tile ranges)'}", flush=True)

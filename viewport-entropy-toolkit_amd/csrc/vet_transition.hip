@@ -88,9 +88,21 @@ int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, dou
             const void* fn = transition_run_kernel<FROM_IDS>(upt, (long)upt * threads == U, threads);
             void* args[] = {(void*)&p};
             HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(threads), args, lds_run, s));
+        } else if (U < (1 << 19) && L.n <= vet::TRANS_BIG_MAX_TILES && !c->tune.t_global) {
+            // more users than the register kernel holds: the bucket hash stays in LDS, the row is cut into ranges of
+            // source tiles whose buckets fit it (k_transition_big); one persistent workgroup per CU
+            long grid = c->n_cu;
+            if (grid > R) grid = R;
+            void* scratch = nullptr;
+            int rc = pooled(c, 8, U4 * 4 * (size_t)grid, &scratch);
+            if (rc) return rc;
+            p.scratch = (uint32_t*)scratch;
+            void* args[] = {(void*)&p};
+            const void* fn = FROM_IDS ? (const void*)vet::k_transition_big<true> : (const void*)vet::k_transition_big<false>;
+            HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(vet::TRANS_BIG_THREADS), args, vet::trans_big_lds_bytes(L.n), s));
         } else {
-            // more users than the LDS holds: bucket hash and per-user words in global scratch, one slice per
-            // persistent workgroup (the reference accepts any number of users, entropy_utils.py:259-332)
+            // lattices of thousands of tiles (or 2^19 users): bucket hash and per-user words in global scratch, one slice
+            // per persistent workgroup (the reference accepts any number of users, entropy_utils.py:259-332)
             const size_t slice = ((size_t)3 * HS + 2 * U4) * 4;
             long grid = (long)c->n_cu * 2;
             if (grid > R) grid = R;
@@ -115,7 +127,8 @@ int launch_transition(vet_plan* pl, const vet::SampleSrc& src, int U, int T, dou
 }  // namespace
 
 int transition_set_attrs(vet_ctx* c) {
-    std::vector<const void*> tk = {(const void*)vet::k_transition_any<false>, (const void*)vet::k_transition_any<true>};
+    std::vector<const void*> tk = {(const void*)vet::k_transition_any<false>, (const void*)vet::k_transition_any<true>,
+                                   (const void*)vet::k_transition_big<false>, (const void*)vet::k_transition_big<true>};
     for (int upt : {1, 2, 4, 8})
         for (int ex = 0; ex < 2; ++ex)
             for (int threads : {128, 0}) {

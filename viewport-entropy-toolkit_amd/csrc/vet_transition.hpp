@@ -229,6 +229,176 @@ __global__ void k_transition_any(const TransParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_transition_big — compute_transition_entropy (entropy_utils.py:213-332) for more users than k_transition_run holds
+// in registers (U > 4096), with the bucket hash still in LDS.  What has to fit is not the users but the BUCKETS —
+// the distinct (source tile, destination tile) pairs of a row — and a source tile of m users has at most min(m, n) of
+// them.  After step (1) (first user and user count per source tile, all users) the source tiles are cut into ranges
+// whose bucket bound sum min(m, n) stays below the hash's capacity, and steps (2)-(5) run once per range over an
+// 8192-slot LDS hash: one pass for a real audience (viewers move little between frames: a few destinations per source
+// tile), two at 9 000 uniformly scattered users, ceil(sum min(m, n) / 4 900) in general.  Per user and pass: one 4-byte
+// read of its packed pair from a per-workgroup global array (written in step (1), L2 resident) and one LDS read of its
+// source tile's pass.  One persistent 1024-thread workgroup per CU.  The global-scratch hash of k_transition_any
+// (dependent global atomics: 0.7 ms for 512 rows of 9 000 users) stays as the fallback for lattices of more than
+// TRANS_BIG_MAX_TILES tiles.
+// LDS: acc f64 [2][20] | first_u, m_cnt, k_cnt, last_fu u32 [n4] | pass u16 [n4] | hkey, hfu, hcnt u32 [8192]
+// ------------------------------------------------------------------------------------------
+constexpr int TRANS_BIG_HS = 8192, TRANS_BIG_MAX_TILES = 2800, TRANS_BIG_THREADS = 1024;
+__host__ __device__ __forceinline__ size_t trans_big_lds_bytes(int n) {
+    const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
+    return 2 * TRANS_ACC * 8 + 4 * n4 * 4 + ((n4 * 2 + 15) & ~(size_t)15) + (size_t)3 * TRANS_BIG_HS * 4 + 64;
+}
+
+template <bool FROM_IDS>
+__global__ __launch_bounds__(TRANS_BIG_THREADS) void k_transition_big(const TransParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int HS = TRANS_BIG_HS, BD = TRANS_BIG_THREADS, NW = BD / WAVE;
+    double* acc2 = (double*)smem;                              // [2][TRANS_ACC]
+    unsigned* first_u = (unsigned*)(acc2 + 2 * TRANS_ACC);     // [n4]
+    const int n4 = (p.n + 3) & ~3;
+    unsigned* m_cnt = first_u + n4;
+    unsigned* k_cnt = m_cnt + n4;
+    unsigned* last_fu = k_cnt + n4;
+    unsigned short* pass_of = (unsigned short*)(last_fu + n4); // [n4] range (pass) of every source tile
+    unsigned* hkey = (unsigned*)((unsigned char*)pass_of + ((n4 * 2 + 15) & ~15));
+    unsigned* hfu = hkey + HS;
+    unsigned* hcnt = hfu + HS;
+    int* n_pass = (int*)(hcnt + HS);
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const size_t U4 = ((size_t)p.U + 3) & ~(size_t)3;
+    unsigned* pc = p.scratch + (size_t)blockIdx.x * U4;       // [U4] the row's packed pairs
+    const long R = (long)p.T - 1;
+    const int cap = HS * 6 / 10 - p.n;                         // bucket bound of a range (one more tile may join: + n at most)
+    const unsigned hs_shift = 32 - 13;
+    bool bad = false;
+    int parity = 0;
+    for (long r = blockIdx.x; r < R; r += gridDim.x, parity ^= 1) {
+        double* acc = acc2 + TRANS_ACC * parity;
+        {   // per-tile words (the barrier at the end of the previous row precedes)
+            const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u), zeros = make_uint4(0u, 0u, 0u, 0u);
+            for (int i = tid; i < n4 / 4; i += BD) {
+                ((uint4*)first_u)[i] = ones; ((uint4*)m_cnt)[i] = zeros; ((uint4*)k_cnt)[i] = zeros; ((uint4*)last_fu)[i] = zeros;
+            }
+            if (tid == 0) ((unsigned long long*)acc)[16] = 0ull;
+        }
+        __syncthreads();
+        // ---- (1) every user: tiles of both frames, first user and user count per source tile
+        for (int u = tid; u < p.U; u += BD) {
+            const int ia = sample_dir<FROM_IDS, false>(p.src, r * (long)p.U + u, bad);
+            const int ib = sample_dir<FROM_IDS, false>(p.src, (r + 1) * (long)p.U + u, bad);
+            unsigned packed = EMPTY_KEY;
+            int pa = -1, cb = -1;
+            if (ia >= 0 && ib >= 0) {           // user present in both frames (entropy_utils.py:259-261)
+                pa = p.nearest[ia]; cb = p.nearest[ib];
+                packed = ((unsigned)pa << 16) | (unsigned)cb;
+                if (first_u[pa] > (unsigned)u) atomicMin(&first_u[pa], (unsigned)u);
+                atomicAdd(&m_cnt[pa], 1u);
+            }
+            const unsigned long long both = __ballot(packed != EMPTY_KEY);
+            if (lane == 0 && both) atomicAdd((unsigned long long*)acc + 16, (unsigned long long)__popcll(both));
+            pc[u] = packed;
+            if (p.pairs) {      // written once: non-temporal
+                __builtin_nontemporal_store(pa, p.pairs + (r * (long)p.U + u) * 2);
+                __builtin_nontemporal_store(cb, p.pairs + (r * (long)p.U + u) * 2 + 1);
+            }
+        }
+        __syncthreads();
+        // ---- ranges of source tiles: tile t goes to pass floor(bound of the tiles before it / cap), bound = min(m, n)
+        if (wv == 0) {
+            unsigned carry = 0u;
+            for (int t0 = 0; t0 < p.n; t0 += WAVE) {
+                const int t = t0 + lane;
+                const unsigned b = t < p.n ? min(m_cnt[t], (unsigned)p.n) : 0u;
+                unsigned v = b;
+#pragma unroll
+                for (int o = 1; o < WAVE; o <<= 1) {
+                    const unsigned up = __shfl_up(v, o, WAVE);
+                    if (lane >= o) v += up;
+                }
+                if (t < p.n) pass_of[t] = (unsigned short)((carry + v - b) / (unsigned)cap);
+                carry += __shfl(v, WAVE - 1, WAVE);
+            }
+            if (lane == 0) *n_pass = carry ? (int)((carry - 1u) / (unsigned)cap) + 1 : 1;
+        }
+        __syncthreads();
+        const int passes = *n_pass;
+        const int N = (int)((const unsigned long long*)acc)[16];
+        const double inv_n = 1.0 / (double)N;
+        const bool tab = p.U <= 4096;
+        double h = 0.0;
+        for (int q = 0; q < passes; ++q) {
+            for (int i = tid; i < HS / 4; i += BD) {
+                ((uint4*)hkey)[i] = make_uint4(~0u, ~0u, ~0u, ~0u); ((uint4*)hfu)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+                ((uint4*)hcnt)[i] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            __syncthreads();
+            // ---- (2) non-first users of the range: bucket insert; the creator counts the bucket into K
+            for (int u = tid; u < p.U; u += BD) {
+                const unsigned key = pc[u];
+                if (key == EMPTY_KEY) continue;
+                const unsigned src = key >> 16;
+                if ((int)pass_of[src] != q || first_u[src] == (unsigned)u) continue;
+                unsigned slot = (key * 2654435761u) >> hs_shift;
+                for (;;) {
+                    const unsigned was = atomicCAS(&hkey[slot], EMPTY_KEY, key);
+                    if (was == EMPTY_KEY) { atomicAdd(&k_cnt[src], 1u); break; }      // a new destination of this source tile
+                    if (was == key) break;
+                    slot = (slot + 1) & (unsigned)(HS - 1);
+                }
+                if (hfu[slot] > (unsigned)u) atomicMin(&hfu[slot], (unsigned)u);
+                atomicAdd(&hcnt[slot], 1u);
+            }
+            __syncthreads();
+            // ---- (3) the first user of every bucket: latest first appearance per source tile, user << 13 | slot
+            for (int u = tid; u < p.U; u += BD) {
+                const unsigned key = pc[u];
+                if (key == EMPTY_KEY) continue;
+                const unsigned src = key >> 16;
+                if ((int)pass_of[src] != q || first_u[src] == (unsigned)u) continue;
+                unsigned slot = (key * 2654435761u) >> hs_shift;
+                while (hkey[slot] != key) slot = (slot + 1) & (unsigned)(HS - 1);
+                if (hfu[slot] == (unsigned)u) atomicMax(&last_fu[src], ((unsigned)u << 13) | slot);
+            }
+            __syncthreads();
+            // ---- (5) cells of the range's source tiles: -(m/N) K (w/m) log2(w/m), w = the latest bucket's count
+            for (int t = tid; t < p.n; t += BD) {
+                if ((int)pass_of[t] != q) continue;
+                const unsigned m = m_cnt[t];
+                if (p.srccount) p.srccount[r * (long)p.n + t] = (int)m;
+                if (!m) continue;
+                const unsigned K = 1u + k_cnt[t];
+                const unsigned w = m <= 1u ? 1u : hcnt[last_fu[t] & 0x1FFFu];
+                const double lq = tab ? p.log2_tab[w] - p.log2_tab[m] : log2((double)w / (double)m);
+                h -= ((double)((unsigned long long)K * w) * inv_n) * lq;
+            }
+            __syncthreads();
+        }
+        h = wave_sum(h);
+        if (lane == 0) acc[wv] = h;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int i = 0; i < NW; ++i) tot += acc[i];
+            double hmax = p.hmax;
+            if (!(N > p.n)) {
+                const double tp = 1.0 / (double)N;          // entropy_utils.py:322-327
+                hmax = (double)N * -tp * (tab ? -p.log2_tab[N] : log2(tp));
+            }
+            double e = tot / hmax;
+            if (N == 0) {
+                e = __builtin_nan("");
+                if (p.status) atomicAdd(&p.status[1], 1);
+            }
+            p.ent_k[r] = e;
+            if (p.common) p.common[r] = N;
+        }
+    }
+    if (p.status) {
+        const unsigned long long anybad = __ballot(bad);
+        if (anybad && lane == 0) atomicAdd(&p.status[0], (int)__popcll(anybad));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_transition_run — the same rows for U <= UPT * blockDim users (everything in LDS), software
 // pipelined: a persistent workgroup takes a contiguous RUN of rows.  The current frame's tiles of row r
 // stay in registers as the prior frame's tiles of row r+1 (every frame is read and quantised once
