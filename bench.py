@@ -148,10 +148,16 @@ def cpu_baseline(mu, mv, tcs, mode, weighted, budget_s):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="GPUs of ONE node, one rank per GPU (N > 1 without an outer launcher starts its own ranks). The two "
+                         "BASELINE.json scaling configs: `--gpus N --workload config4` (one video per GPU, one RCCL gather: weak "
+                         "scaling) and `--gpus N --workload config5 --shard frames` (one video cut along the frame axis with a "
+                         "one-frame halo: strong scaling); the N > 1 line carries per_rank step / kernel / gather times")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS),
+                    help="config2..config5 = BASELINE.json configs[1..4] (config3 = the single-GPU roofline config, the default); "
+                         "config3u = config3 with use_weight_distribution=False; *x64 = 64 videos per GPU in one launch")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -29,13 +29,15 @@ for w in config2x64u config2x64t config5x64; do
   line ${w}_loop --workload $w --loop --no-cpu-baseline || exit 1
 done
 line config2x64_loop --workload config2x64 --loop --no-cpu-baseline || exit 1
-# per-lattice tables instead of the fused one (VET_NO_FUSED=1) and the experimental persistent kernel (VET_ROWS=1)
+# per-lattice tables instead of the fused one (VET_NO_FUSED=1)
 for w in config4 defaults config2x64; do VET_NO_FUSED=1 line ${w}_per_lattice_tables --workload $w --no-cpu-baseline --no-api || exit 1; done
-for w in config3 config4; do VET_ROWS=1 line ${w}_rows_kernel --workload $w --no-cpu-baseline --no-api || exit 1; done
 timeout -k 10 300 python3 tools/precise_timing.py > gpurun_out/$TAG/formulation_timing.txt 2>&1 || echo "formulation timing failed"
 timeout -k 10 300 python3 tools/transition_any_timing.py > gpurun_out/$TAG/transition_any_timing.txt 2>&1 || echo "transition_any timing failed"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/transition_any_trace -- python3 tools/transition_any_timing.py > /dev/null 2>&1 && cp $(ls gpurun_out/$TAG/transition_any_trace/*/*_kernel_stats.csv | head -1) gpurun_out/$TAG/transition_any_kernel_stats.csv
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/default_trace -- python3 bench.py --no-cpu-baseline --no-api > gpurun_out/$TAG/default_bench_under_rocprof.json 2> gpurun_out/$TAG/default_trace.err || { echo "rocprof default bench failed"; exit 1; }
 cp $(ls gpurun_out/$TAG/default_trace/*/*_kernel_stats.csv | head -1) gpurun_out/$TAG/default_bench_kernel_stats.csv
 for w in config3 config3u config4 config5; do cp $(ls gpurun_out/$TAG/pmc/$w/trace/*/*_kernel_stats.csv | head -1) gpurun_out/$TAG/pmc_${w}_kernel_stats.csv; done
+# L2 / L1 counters of the table kernel at config 3 and SQ instruction mix (config 3 and 4): pmc3.sh, pmc_sq.sh
+bash tools/pmc3.sh config3 $TAG/pmc_stalls_config3 > gpurun_out/$TAG/pmc3_config3.log 2>&1 && cp gpurun_out/$TAG/pmc_stalls_config3/summary.json gpurun_out/$TAG/config3_pmc_stalls.json
+for w in config3 config4 config5; do bash tools/pmc_sq.sh $w $TAG/pmc_sq_$w > gpurun_out/$TAG/pmc_sq_$w.log 2>&1 && cp gpurun_out/$TAG/pmc_sq_$w/summary.json gpurun_out/$TAG/${w}_pmc_sq.json; done
 echo "refresh done"
