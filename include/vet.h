@@ -137,7 +137,10 @@ int64_t vet_plan_n_dirs(const vet_plan *plan);
  * spacing, large power factors — run `ftable` (calls large enough for a table) or `precise`; those two
  * sum in FP64 in a fixed order: `ftable` sorts every frame's list of distinct rows, gives every wave a histogram
  * of its own and adds those in wave order (bit-identical run to run, under any user permutation of frames of
- * <= 2048 users, frame split or GPU count); `precise` sums the users in column order, as the reference does
+ * <= 2048 users, frame split or GPU count — as measured on gfx950: where two rows of one wave instruction hit the
+ * same tile the result also rests on the LDS servicing the lanes of a ds_add_f64 in lane order, which the hardware
+ * does and the ISA does not promise; tests/test_hip_contract.py and tools/repeat_check.py are the guard);
+ * `precise` sums the users in column order, as the reference does
  * (as the resolver of `ftable`: in ascending direction order).
  * The reference's NaN frames: every tile with distance < fov/2 is a key of the reference's per-frame dict,
  * also when ((max - d) / max) ** power_factor underflows to exactly 0.0 (entropy_utils.py:131-135), and a key
