@@ -15,7 +15,7 @@ cases = [("spatial", 1024, 3000, [500], True, "random_walk"), ("spatial", 1024, 
          ("spatial", 1024, 3000, [500], False, "random_walk"), ("spatial", 300, 500, [20, 50, 100, 250, 1000], True, "uniform"),
          ("transition", 512, 10000, [200], True, "random_walk"), ("transition", 512, 4000, [200], True, "clustered"),
          ("transition", 300, 999, [200], True, "uniform"), ("transition", 1500, 300, [50], True, "random_walk"),
-         ("transition", 5000, 40, [50, 20], True, "random_walk"),
+         ("transition", 5000, 40, [50, 20], True, "random_walk"), ("transition", 9000, 24, [200], True, "uniform"),      # round 4: k_transition_big
          # round 3: FP table (sorted rows, per-wave histograms), marker plans with the in-call resolver, fused + FP mixes
          ("spatial", 1024, 2000, [500], True, "random_walk", 120.0, 20.0), ("spatial", 256, 2000, [500], True, "clustered", 10.0, 2.0),
          ("spatial", 300, 1500, [50, 100], True, "random_walk", 120.0, 30.0), ("spatial", 100, 800, [50], True, "uniform", 120.0, 50.0),
