@@ -486,6 +486,16 @@ def main():
                 ids = (mv_h * 200).astype(np.int64) * 101 + (mu_h * 100).astype(np.int64)
                 rows = np.sort(alias.reshape(-1)[ids], axis=1)
                 distinct = 1 + (np.diff(rows, axis=1) != 0).sum(1)
+                # how many row loads a walk over GROUPS of F consecutive frames could share (distinct rows of a group /
+                # sum of its frames' distinct rows; first 2048 frames): the reuse the round-4 joint-walk experiment had
+                # to live on (profiles/r04/v4_two_kernel_joint_walk_experiment.log)
+                reuse = {}
+                head = rows[:2048]
+                for F in (2, 4, 8, 16):
+                    g = head[: len(head) // F * F].reshape(-1, F * head.shape[1])
+                    g = np.sort(g, axis=1)
+                    union = 1 + (np.diff(g, axis=1) != 0).sum(1)
+                    reuse[str(F)] = float(union.sum() / max(distinct[: len(head) // F * F].sum(), 1))
                 entries = float(distinct.sum()) * cap * sum(n_lat) * n_batch / launches_per_step
                 cu, clk = 256, 2.4e9
                 lds_rate = 64 / 6.6 * clk * cu                      # conflict-free ds_add_u64: 6.6 clk per wave (probed)
@@ -494,6 +504,7 @@ def main():
                 out["roofline"]["secondary"] = {
                     "bound": "row gather (6 B per entry through L2 / Infinity Cache) and one ds_add_u64 per entry",
                     "distinct_directions_per_frame": float(distinct.mean()), "users_per_frame": U,
+                    "row_reuse_over_frame_groups": reuse,
                     "entries_per_launch": entries, "gathered_bytes_per_launch": 6 * entries,
                     "achieved": 6 * entries / (avg_kernel_ms * 1e-3) / 1e9 / cu, "unit": "GB/s per CU",
                     "guide_rates_GBps_per_cu": {"xcd_l2": [66, 73], "infinity_cache": 33.5, "hbm": [23, 24]},
