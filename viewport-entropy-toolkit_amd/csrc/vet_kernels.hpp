@@ -21,7 +21,9 @@
 //                                              k_spatial_u      generic fallback (LUT gathered from global memory)
 //   vet_transition.hip  vet_transition.hpp     k_transition_run per frame pair: (prior tile, current tile) pairs -> bucket
 //                                                               statistics in LDS -> transition entropy; persistent workgroups
-//                                              k_transition_any the same for any number of users
+//                                              k_transition_big more than 4096 users: the bucket hash in LDS, the row cut into
+//                                                               ranges of source tiles whose buckets fit it
+//                                              k_transition_any fallback for lattices of thousands of tiles (hash in global scratch)
 //   (several units)     vet_finalize.hpp       k_log2_table, k_finalize*   log2(k) table; mean over a plan's lattices
 // Shared, kernel-free headers: vet_layout.hpp (table / histogram layout constants), vet_common.hpp (wave helpers, the
 // sample -> direction-id quantiser), vet_weights.hpp (FoV weight, weighted frame entropy), vet_host.hpp (host state).
