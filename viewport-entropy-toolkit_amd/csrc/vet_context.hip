@@ -64,6 +64,7 @@ void Tuning::from_environment() {
     no_fused = env_flag("VET_NO_FUSED");
     fused_single = env_flag("VET_FUSED");
     lut_occ8 = env_int("VET_LUT_OCC8", 0, 1, 0);
+    fused_narrow = env_int("VET_FUSED_NARROW", 0, 1, 1);
 }
 
 int collect_profile(vet_ctx* c) {

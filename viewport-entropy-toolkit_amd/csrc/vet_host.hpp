@@ -65,6 +65,7 @@ struct Tuning {
     int no_fused = 0;           // VET_NO_FUSED
     int fused_single = 0;       // VET_FUSED: fused table also for one-lattice plans
     int lut_occ8 = 0;           // VET_LUT_OCC8
+    int fused_narrow = 1;       // VET_FUSED_NARROW: 8-lane rows for fused rows of 65..96 entries
     void from_environment();
 };
 

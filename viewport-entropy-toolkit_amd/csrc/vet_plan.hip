@@ -352,6 +352,9 @@ int ensure_fused(vet_plan* pl, hipStream_t s) {
     }
     F.gs_log2 = 1;
     while (F.gs_log2 < 4 && (4 << F.gs_log2) < longest) ++F.gs_log2;
+    // rows of 65..96 entries: three 32-entry blocks of an 8-lane group instead of two 64-entry blocks, the second mostly
+    // empty (config 4: 88-94 entries: 128 -> 96 slots per row walk)
+    if (longest > 64 && longest <= 96 && c->tune.fused_narrow) F.gs_log2 = 3;
     if (c->tune.gs_log2) F.gs_log2 = c->tune.gs_log2;
     F.interleaved = F.gs_log2 == 4 && 4 * longest >= 3 * 64 && c->tune.tab_interleave != 0;
     p.stride = stride; p.w = F.d_w; p.idx = F.d_i; p.meta = F.d_meta; p.maxcount = nullptr;

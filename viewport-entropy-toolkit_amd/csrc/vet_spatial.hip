@@ -79,7 +79,14 @@ const void* spatial_w_kernel(int wmode, int R, bool precise = false) {
 #define VET_FUSED_UN 4
 #endif
 template <bool FROM_IDS>
-const void* lut_kernel_fused(bool il, bool occ8, bool dedup) {
+const void* lut_kernel_fused(bool il, bool occ8, bool dedup, bool narrow = false) {
+    // narrow: rows of 8-lane groups (32-entry blocks; fused rows of 65..96 entries fill three of them instead of two half-empty
+    // 64-entry ones): two rows in flight per lane group keep a wave at 16 rows per step, as four do with 16-lane groups
+    if (narrow) {
+#define VET_PICKN(O, D) if (occ8 == O && dedup == D) return (const void*)vet::k_spatial_lut<FROM_IDS, 2, false, O, D, false, true>
+        VET_PICKN(false, false); VET_PICKN(true, false); VET_PICKN(false, true); VET_PICKN(true, true);
+#undef VET_PICKN
+    }
 #define VET_PICK(I, O, D) if (il == I && occ8 == O && dedup == D) return (const void*)vet::k_spatial_lut<FROM_IDS, VET_FUSED_UN, I, O, D, false, true>
     VET_PICK(false, false, false); VET_PICK(false, true, false); VET_PICK(true, false, false); VET_PICK(true, true, false);
     VET_PICK(false, false, true); VET_PICK(false, true, true); VET_PICK(true, false, true); VET_PICK(true, true, true);
@@ -283,7 +290,7 @@ int launch_lut_fused(vet_plan* pl, const vet::SampleSrc& src, int U, int T, cons
     {
         ProfScope ps(c, s, KID_SPATIAL);
         void* args[] = {(void*)&q};
-        HIP_TRY(hipLaunchKernel(lut_kernel_fused<FROM_IDS>(F.interleaved, occ8, dedup), dim3((unsigned)blocks), dim3(threads), args, lds, s));
+        HIP_TRY(hipLaunchKernel(lut_kernel_fused<FROM_IDS>(F.interleaved, occ8, dedup, F.gs_log2 == 3), dim3((unsigned)blocks), dim3(threads), args, lds, s));
         HIP_TRY(hipGetLastError());
     }
 #if VET_STAGE_CYCLES
@@ -539,6 +546,8 @@ int spatial_set_attrs(vet_ctx* c) {
     for (int v = 0; v < 8; ++v) {
         ATTR_TRY(lut_kernel_fused<false>(v & 1, v & 2, v & 4), c->lds_max);
         ATTR_TRY(lut_kernel_fused<true>(v & 1, v & 2, v & 4), c->lds_max);
+        ATTR_TRY(lut_kernel_fused<false>(false, v & 2, v & 4, true), c->lds_max);
+        ATTR_TRY(lut_kernel_fused<true>(false, v & 2, v & 4, true), c->lds_max);
         ATTR_TRY(lut_kernel<false>(v & 1, v & 2, v & 4), c->lds_max);
         ATTR_TRY(lut_kernel<true>(v & 1, v & 2, v & 4), c->lds_max);
         if (!(v & 2)) {
