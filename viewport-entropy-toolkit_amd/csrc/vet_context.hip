@@ -63,7 +63,7 @@ void Tuning::from_environment() {
     t_hs_pct = env_int("VET_T_HS_PCT", 100, 400, 200);     // bucket-hash slots per 100 users (100: no gain, 43.3 vs 43.7 us)
     no_fused = env_flag("VET_NO_FUSED");
     fused_single = env_flag("VET_FUSED");
-    lut_occ8 = env_int("VET_LUT_OCC8", 0, 1, 0);
+    lut_occ8 = env_int("VET_LUT_OCC8", 0, 1, -1);
     fused_narrow = env_int("VET_FUSED_NARROW", 0, 1, 1);
 }
 

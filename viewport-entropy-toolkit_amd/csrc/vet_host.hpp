@@ -64,7 +64,7 @@ struct Tuning {
     int t_hs_pct = 200;         // VET_T_HS_PCT
     int no_fused = 0;           // VET_NO_FUSED
     int fused_single = 0;       // VET_FUSED: fused table also for one-lattice plans
-    int lut_occ8 = 0;           // VET_LUT_OCC8
+    int lut_occ8 = -1;          // VET_LUT_OCC8 (fused table kernel: -1 by shape)
     int fused_narrow = 1;       // VET_FUSED_NARROW: 8-lane rows for fused rows of 65..96 entries
     void from_environment();
 };

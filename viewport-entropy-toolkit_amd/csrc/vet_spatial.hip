@@ -280,7 +280,10 @@ int launch_lut_fused(vet_plan* pl, const vet::SampleSrc& src, int U, int T, cons
     } else {
         q.FPW = 1; q.UC = 1;
     }
-    const bool occ8 = c->tune.lut_occ8 != 0;
+    // 8 workgroups per CU (64 VGPRs) pay for the narrow kernel on a single video of many users (two rows in flight: few
+    // registers; config 4 0.146 -> 0.142 ms), not for the 16-lane kernel with four rows in flight (defaults +5 %), for
+    // batches (+1 %) or for frames without the set (config 2 +2 %)
+    const bool occ8 = c->tune.lut_occ8 >= 0 ? c->tune.lut_occ8 != 0 : (F.gs_log2 == 3 && !d_videos && dedup);
 #if VET_STAGE_CYCLES
     DevBuf dbg;                               // development builds: cycles per stage (thread 0 of every workgroup), synchronous
     HIP_TRY(dbg.alloc(32));
