@@ -83,3 +83,17 @@ def test_one_hip_runtime_is_loaded():
     assert out.returncode == 0, out.stderr[-1500:]
     n, ok = out.stdout.split()[-2:]
     assert n == "1" and ok in ("True", "system"), out.stdout
+
+
+def test_environment_is_read_in_one_place_only():
+    """The tuning environment is parsed once, in vet_create (vet_context.hip): no launch path may call getenv, and nothing
+    experimental (tools/experiments/) is compiled into the library."""
+    csrc = ROOT / "viewport-entropy-toolkit_amd" / "csrc"
+    for f in list(csrc.glob("*.hip")) + list(csrc.glob("*.hpp")):
+        text = f.read_text()
+        code = "\n".join(line.split("//")[0] for line in text.splitlines())
+        if f.name != "vet_context.hip":
+            assert "getenv" not in code, f"{f.name} reads the environment"
+        assert "experiments/" not in code and "k_spatial_rows" not in code and "k_spatial_walk" not in code, f.name
+    mk = (csrc / "Makefile").read_text()
+    assert "experiments" not in mk
