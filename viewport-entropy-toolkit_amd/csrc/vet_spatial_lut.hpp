@@ -236,27 +236,23 @@ struct LutParams {
 // L = sum v log2 v together, then H = log2 S - L / S: one log2 per tile, one divide per lattice.  Against the
 // term-by-term form -sum (v/S) log2 (v/S) the cancellation costs ~60 ulp ABSOLUTE (2e-14); integer formulations only
 // run on plans whose every frame has an entropy above ~1e-3 (k_row_stats: the bound 36.5 q k / (2 S H) <= 1e-7 needs
-// it), i.e. <= 2e-11 relative.  Canonical order: 64-tile chunks, a fixed DPP tree inside a chunk, chunks in order ->
-// the same bits whatever the kernel, the frames per workgroup or the launch geometry.
+// it), i.e. <= 2e-11 relative.  Canonical order: every lane sums its tiles lane, lane + 64, ... in order, then one fixed
+// DPP tree -> the same bits whatever the kernel, the frames per workgroup or the launch geometry.
 //   val(t): the histogram value of tile t of this lattice;  wrow: this frame's row of the weights output or null.
 // ------------------------------------------------------------------------------------------
 template <class V>
 __device__ __forceinline__ double lattice_entropy_int(int n, V val, double hmax, double* wrow, double inv_unit) {
     const int lane = lane_id();
     unsigned long long hi = 0ull, lo = 0ull;
-    double L = 0.0;
-    for (int t0 = 0; t0 < n; t0 += WAVE) {
-        const int t = t0 + lane;
-        double term = 0.0;
-        if (t < n) {
-            const unsigned long long v = val(t);
-            hi += v >> 32; lo += v & 0xFFFFFFFFull;
-            const double vd = (double)v;
-            if (v != 0ull) term = vd * log2(vd);
-            if (wrow) __builtin_nontemporal_store(vd * inv_unit, wrow + t);
-        }
-        L += wave_total(term);
+    double L = 0.0;                             // per lane over its tiles lane, lane + 64, ...; one tree at the end
+    for (int t = lane; t < n; t += WAVE) {
+        const unsigned long long v = val(t);
+        hi += v >> 32; lo += v & 0xFFFFFFFFull;
+        const double vd = (double)v;
+        if (v != 0ull) L += vd * log2(vd);
+        if (wrow) __builtin_nontemporal_store(vd * inv_unit, wrow + t);
     }
+    L = wave_total(L);
     hi = wave_total(hi); lo = wave_total(lo);
     const double S = (double)(hi + (lo >> 32)) * 4294967296.0 + (double)(lo & 0xFFFFFFFFull);
     if (!(S > 0.0)) return 0.0;                 // no tile in any user's FoV: the reference sums over an empty dict
