@@ -490,6 +490,47 @@ def test_config5_transition_full_size_properties(native, engine):
     plan.close()
 
 
+@pytest.mark.parametrize("kind", ["walk", "uniform"])
+def test_transition_large_audience_properties(native, engine, kind):
+    """k_transition_big at scale: 9 000 users x 600 frames, tile_counts=[200, 50] (two lattices: the mean, lattice 0's
+    pairs and source counts).  Size-independent properties: output selection does not change the entropy, a frame shard
+    with its one-frame halo reproduces its rows bit for bit, pairs are the nearest tiles of both frames, source counts sum
+    to the users present in both frames, repeated calls agree bit for bit; and the reference's literal dict walk on sampled
+    rows.  Random walks need one range of source tiles per row, uniformly scattered users several."""
+    U, T = 9000, 600
+    rng = np.random.default_rng(11)
+    if kind == "walk":
+        mu = np.mod(0.5 + np.cumsum(rng.normal(0, 0.01, (T, U)), axis=0), 1.0)
+        mv = np.clip(0.5 + np.cumsum(rng.normal(0, 0.005, (T, U)), axis=0), 0.0, 1.0)
+    else:
+        mu = rng.random((T, U))
+        mv = np.clip(np.arccos(1.0 - 2.0 * rng.random((T, U))) / np.pi, 0.0, 1.0)
+    gone = rng.random((T, U)) < 0.03
+    gone[:, 0] = False
+    mu[gone] = np.nan
+    plan = make_plan(native, engine, [200, 50])
+    a = plan.transition(mu=mu, mv=mv, want_pairs=True, want_srccount=True)
+    b = plan.transition(mu=mu, mv=mv, want_pairs=False)
+    assert np.array_equal(a["entropy"], b["entropy"])
+    both = ~gone[:-1] & ~gone[1:]
+    assert np.array_equal(a["common"], both.sum(1)) and np.array_equal(a["srccount"].sum(1), both.sum(1))
+    d = plan.transition(mu=mu[200:451], mv=mv[200:451], want_pairs=False)           # rows [200, 450) need frames [200, 450]
+    assert np.array_equal(d["entropy"], a["entropy"][200:450])
+    near = plan.read_nearest(0).reshape(201, 101)
+    safe_mu, safe_mv = np.where(gone, 0.0, mu), np.where(gone, 0.0, mv)
+    tile = near[(safe_mv * 200).astype(int), (safe_mu * 100).astype(int)]
+    assert np.array_equal(a["pairs"][..., 0], np.where(both, tile[:-1], -1))
+    assert np.array_equal(a["pairs"][..., 1], np.where(both, tile[1:], -1))
+    near50 = plan.read_nearest(1).reshape(201, 101)
+    tile50 = near50[(safe_mv * 200).astype(int), (safe_mu * 100).astype(int)]
+    for r in rng.integers(0, T - 1, 6):
+        m = both[r]
+        e = 0.5 * (vo.transition_entropy_pairs(tile[r][m], tile[r + 1][m], 201) +
+                   vo.transition_entropy_pairs(tile50[r][m], tile50[r + 1][m], 51))
+        np.testing.assert_allclose(a["entropy"][r], e, rtol=RTOL)
+    plan.close()
+
+
 def test_formulation_is_a_pure_function_of_the_call(native, engine):
     """Policy 0 picks table or sweep from the call's shape alone: a small video sweeps however many
     videos the plan has seen and whether or not its tables exist, a large one gathers, and the same
