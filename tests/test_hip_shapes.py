@@ -395,8 +395,19 @@ def test_batch_with_fp_tables_and_marker_plans(native, engine, tcs, fov, power):
     shapes = [(8, 30), (200, 40), (33, 7), (300, 12), (1, 5), (130, 25)]
     vids = [video(u, t, seed=5 * i + u) for i, (u, t) in enumerate(shapes)]
     plan = plan_for(native, engine, tcs, policy=1, fov=fov, power=power)
+    plan.spatial_batch(vids, want_assign=True, check=False)          # builds the tables
+    engine.profile_enable(True)
+    engine.profile_reset()
     got = plan.spatial_batch(vids, want_assign=True, check=False)
+    launches = engine.profile_get("k_spatial")[1]
+    engine.profile_enable(False)
     assert plan.last_formulation(0) == "ftable"
+    if power <= 30.0:
+        # no weight below 2^-1048: in-FoV weights below FP32 range are stored as the smallest subnormal, the table holds no
+        # marker, nothing needs the resolver and the whole batch is ONE launch
+        assert launches == 1, launches
+    else:
+        assert launches >= len(vids)                                  # marker plans: video by video, plus their resolvers
     for (mu, mv), g in zip(vids, got):
         one = plan.spatial(mu=mu, mv=mv, check=False)
         assert np.array_equal(g["entropy"], one["entropy"], equal_nan=True)
