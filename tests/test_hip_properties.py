@@ -75,3 +75,40 @@ def test_hip_matches_oracle(native, engine, pr):
             np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=2e-7 if fp else 1e-8, atol=1e-15)
     finally:
         plan.close()
+
+
+big_problem = st.fixed_dictionaries(dict(
+    U=st.integers(4097, 7000), T=st.integers(2, 4), seed=st.integers(0, 2 ** 31 - 1),
+    p_absent=st.sampled_from([0.0, 0.05, 0.6]), tc=st.sampled_from([2, 20, 50, 200, 1000]),
+    spread=st.sampled_from(["uniform", "few", "pixel"])))
+
+
+@settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(big_problem)
+def test_transition_beyond_4096_users_matches_the_dict_walk(native, engine, pr):
+    """k_transition_big (the bucket hash in LDS, the row cut into ranges of source tiles) on random problems: users
+    scattered over the sphere (many buckets: several ranges), packed into a few directions (buckets of thousands of
+    users) or on exact pixel corners; against the reference's literal dict walk."""
+    rng = np.random.default_rng(pr["seed"])
+    U, T = pr["U"], pr["T"]
+    if pr["spread"] == "uniform":
+        mu, mv = rng.random((T, U)), rng.random((T, U))
+    elif pr["spread"] == "few":
+        mu = rng.choice(rng.random(7), (T, U))
+        mv = rng.choice(rng.random(5), (T, U))
+    else:
+        mu = rng.integers(0, 101, (T, U)) / 100.0
+        mv = rng.integers(0, 201, (T, U)) / 200.0
+    gone = rng.random((T, U)) < pr["p_absent"]
+    gone[:, 0] = False
+    mu[gone] = np.nan
+    mv[gone] = np.nan
+    plan = native.Plan(engine, [vo.fibonacci_lattice(pr["tc"])], 120.0, 2.0, True, 100, 200)
+    try:
+        res = plan.transition(mu=mu, mv=mv, want_srccount=True)
+        ent, pairs = vo.transition_series(mu, mv, 100, 200, [pr["tc"]], closed_form=False)
+        assert np.array_equal(res["pairs"], pairs)
+        assert np.array_equal(res["common"], (~gone[1:] & ~gone[:-1]).sum(1))
+        np.testing.assert_allclose(res["entropy"], ent, rtol=1e-9, equal_nan=True)
+    finally:
+        plan.close()
