@@ -50,6 +50,11 @@ def test_no_cpu_fallback_without_device():
     from viewport_entropy_toolkit import Vector
     with pytest.raises(_native.NativeUnavailable):
         compute_spatial_entropy({"a": Vector(1.0, 0.0, 0.0)}, generate_fibonacci_lattice(20), EntropyConfig())
+    from viewport_entropy_toolkit.utilities import vector_angle_distance, find_angular_distances
+    with pytest.raises(_native.NativeUnavailable):          # not wrapped into the reference's ValidationError
+        vector_angle_distance(Vector(1.0, 0.0, 0.0), Vector(0.0, 1.0, 0.0))
+    with pytest.raises(_native.NativeUnavailable):
+        find_angular_distances(Vector(1.0, 0.0, 0.0), generate_fibonacci_lattice(20))
 
 
 def test_product_does_not_import_the_oracle():

@@ -51,6 +51,8 @@ def vector_angle_distance(v1: Vector, v2: Vector) -> float:
     try:
         pair = np.array([[v1.x, v1.y, v1.z], [v2.x, v2.y, v2.z]], dtype=np.float64)
         return np.float64(_native.Engine.default().angular_distances(pair[:1], pair[1:])[0, 0])
+    except _native.NativeUnavailable:
+        raise                                   # no HIP extension / no device: fail loudly, there is no CPU path
     except Exception as e:
         raise ValidationError(f"Error calculating vector angle: {str(e)}")
 
@@ -61,6 +63,8 @@ def find_angular_distances(vector: Vector, tile_centers: List[Vector]) -> np.nda
         return np.array([])
     try:
         d = _native.Engine.default().angular_distances(_xyz([vector]), _xyz(tile_centers))[0]
+    except _native.NativeUnavailable:
+        raise
     except Exception as e:
         raise ValidationError(f"Error calculating vector angle: {str(e)}")
     return np.column_stack([np.arange(len(tile_centers), dtype=np.float64), d])
