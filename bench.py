@@ -146,6 +146,33 @@ def cpu_baseline(mu, mv, tcs, mode, weighted, budget_s):
     return out
 
 
+def expected_step_ms(workload, mode, strong, world, U, T_total, kernel_ms_max, gather_ms_max, pipelined):
+    """The model of an N-GPU step, printed beside the measurement.
+    Weak scaling (one video per rank, BASELINE config 4): no data-path collective, every rank runs the 1-GPU kernel on its
+    own video; the gather of the entropy series (80 KB per rank at config 4) is enqueued behind the kernel and overlaps
+    the next step's kernel: step = max(kernel + enqueue, gather) -> efficiency 1 as long as the gather is shorter than
+    the kernel (0.142 ms at config 4).
+    Strong scaling of transition mode (one video cut into N frame blocks, BASELINE config 5): k_transition_run takes
+    9 us + 6.8 us per row of a persistent workgroup (tools/transition_scaling.py) on 8 x 256 workgroup slots, so the
+    kernel of a rank with R/N rows takes 9 + 6.8 * ceil(R / N / 2048) us — 42 us at N = 1, 29 at 2, 16 at 4 and at 8
+    (one row per workgroup is the floor) — and the step can never be shorter than the gather: config 5 is too small to
+    scale (48.7 us on ONE GPU); it is reported, not tuned for."""
+    enqueue_ms = 0.006                                   # host enqueue + stream gaps of a step (1-GPU: step - kernel)
+    if strong and mode == "transition":
+        rows = T_total - 1
+        per_rank = -(-rows // world)
+        slots = 8 * 256
+        kernel = (9.0 + 6.8 * -(-per_rank // slots)) * 1e-3 if U <= 512 else kernel_ms_max
+        model = "9 us + 6.8 us x ceil(rows per rank / 2048 workgroup slots), + enqueue; step >= gather"
+    else:
+        kernel = kernel_ms_max                           # same shape per rank as at N = 1
+        model = "1-GPU kernel per rank (this run's slowest rank) + enqueue; the gather overlaps the next step's kernel"
+    body = kernel + enqueue_ms
+    step = max(body, gather_ms_max) if pipelined else body + gather_ms_max
+    return {"step_ms": step, "kernel_ms": kernel, "gather_ms": gather_ms_max, "enqueue_ms": enqueue_ms, "model": model,
+            "limiter": "gather" if (pipelined and gather_ms_max > body) else "kernel"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1,
@@ -474,6 +501,9 @@ def main():
                                "gather": f"one {'RCCL' if backend == 'nccl' else backend} gather of {Rg} FP64 per rank and step"
                                          + (", overlapped with the next step's kernel inside the timed region" if pipelined else ""),
                                "note": "gather_ms is the gather alone (in order, after the timed region); step_ms is each rank's own clock"}
+            # what the curve should look like, so that a SCALE point can be judged the moment it exists
+            out["per_rank"]["expected"] = expected_step_ms(args.workload, mode, strong, world, U, T_total,
+                                                            float(per_rank[:, 1].max()), float(per_rank[:, 2].max()), pipelined)
         # besides the HBM figure, say what the run formulation is really bound by
         if mode == "spatial" and weighted and k_n:
             n_lat = [2 * (tc // 2) + 1 for tc in tcs]
@@ -516,6 +546,40 @@ def main():
                 out["roofline"]["secondary"] = {
                     "bound": "fp64 valu (13.5 flop per tile and sample, SURVEY.md 8d)", "flop_per_launch": flop,
                     "achieved": flop / (avg_kernel_ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s"}
+        if mode == "transition" and k_n:
+            # Transition mode's own limiter: the per-row LDS work of k_transition_run (atomics on the per-tile words and the
+            # bucket hash, five barrier-separated steps) — not bytes.  LDS wave instructions and LDS-busy cycles per launch
+            # come from the SQ counter passes of tools/pmc_sq.sh (profiles/pmc_sq.json, valid for the kernel sources they
+            # were collected on); the latency model is tools/transition_scaling.py's fit.
+            rows_launch = R * n_batch / launches_per_step
+            cu, clk, slots = 256, 2.4e9, 8 * 256
+            sq, sq_src = None, None
+            qf = ROOT / "profiles" / "pmc_sq.json"
+            if qf.exists() and args.data == "random_walk":
+                try:
+                    rec = json.loads(qf.read_text()).get(args.workload, {})
+                    if rec.get("kernel_src_sha") == kernel_src_sha():
+                        sq, sq_src = rec, {"file": "profiles/pmc_sq.json", "kernel_src_sha": rec.get("kernel_src_sha")}
+                except Exception:  # noqa: BLE001
+                    sq = None
+            sec = {"bound": "LDS wave instructions of the row's five steps and their round trips (16 waves per CU)",
+                   "rows_per_launch": rows_launch,
+                   "latency_model": {"what": "9 us + 6.8 us per row of a persistent workgroup, 2048 workgroup slots "
+                                             "(tools/transition_scaling.py, 512 users)",
+                                     "ms": (9.0 + 6.8 * rows_launch / slots) * 1e-3 if (U <= 512 and n_batch == 1) else None}}
+            if sq:
+                insts, active, conflict = sq["SQ_INSTS_LDS"], sq["SQ_LDS_IDX_ACTIVE"], sq["SQ_LDS_BANK_CONFLICT"]
+                sec.update({
+                    "lds_wave_instructions_per_row": insts / rows_launch,
+                    "lds_cycles_per_instruction": {"measured": active / insts, "without_bank_conflicts": (active - conflict) / insts},
+                    "sol_ms": {"lds_busy_as_measured": active / (cu * clk) * 1e3,
+                               "lds_busy_conflict_free": (active - conflict) / (cu * clk) * 1e3},
+                    "frac_of_sol": (active - conflict) / (cu * clk) / (avg_kernel_ms * 1e-3),
+                    "lds_busy_share_of_kernel": active / (cu * clk) / (avg_kernel_ms * 1e-3),
+                    "provenance": sq_src,
+                    "reading": "the LDS is busy a third of the kernel: the row's dependent LDS round trips (a wave waits in "
+                               "s_waitcnt for half of its life) bound it, not LDS throughput and not bytes"})
+            out["roofline"]["secondary"] = sec
         if world == 1 and mode == "spatial" and weighted and n_batch == 1:
             # the same video with use_weight_distribution=False (every user counts 1 on its nearest
             # tile): the HBM-streaming formulation of the path, reported beside the headline

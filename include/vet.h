@@ -25,9 +25,10 @@
  *     VET_STREAM_LEGACY; any other value is used as the hipStream_t it is.
  *     Device-pointer entry points only enqueue work; they do not synchronise.  A context — and
  *     every plan of it — is single-threaded and must not be in use on two streams at once: its
- *     scratch (the batch descriptors, the K > 1 workspace, the transition scratch, the resolve
- *     list of an FP table) is shared by all calls, so calls on different streams must be
- *     synchronised in between.  A plan's tables are complete (stream synchronised) when the
+ *     scratch (the K > 1 workspace, the transition scratch, the resolve list of an FP table) is
+ *     shared by all calls, so calls on different streams must be synchronised in between.
+ *     (Batch descriptors are not part of that scratch: each batch call stages them in its own
+ *     slot of an event-guarded ring, so back-to-back batch calls need no synchronisation.)  A plan's tables are complete (stream synchronised) when the
  *     call that built them returns; a result handle (vet_result) may outlive its context.
  *   - there is no CPU fallback: without a gfx950 device vet_create() fails.
  */
@@ -41,7 +42,8 @@
 extern "C" {
 #endif
 
-#define VET_VERSION 130 /* 0.1.3: + vet_angular_distances; every in-FoV tile is a key under every formulation */
+#define VET_VERSION 140 /* 0.1.4: tile_weights values at the reference's precision under every formulation
+                           (+ vet_plan_set_raw_weights); batch descriptors in an event-guarded ring */
 #define VET_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy: the null stream with legacy ordering */
 
 enum {
@@ -69,7 +71,8 @@ int vet_synchronize(vet_ctx *ctx);
 int vet_profile_enable(vet_ctx *ctx, int on);
 int vet_profile_reset(vet_ctx *ctx);
 /* kernel ids: 0 k_grid_dirs, 1 k_nearest_lut, 2 k_spatial (any variant), 3 k_transition,
- *             4 k_finalize, 5 k_wtab (direction weight table build) */
+ *             4 k_finalize, 5 k_wtab (direction weight table build),
+ *             6 k_weights (weights-only pass of the precise sweep: the d_weights output / fetched weight rows) */
 int vet_profile_get(vet_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
 const char *vet_kernel_name(int kernel_id);
 
@@ -157,6 +160,14 @@ int64_t vet_plan_n_dirs(const vet_plan *plan);
  * vet_plan_error_bounds: the proven relative entropy error bounds of lattice k for the table and the
  * sweep (at <= 1024 users) formulations; inf = a frame exists whose entropy no fixed point resolves. */
 int vet_plan_set_table_policy(vet_plan *plan, int policy);
+/* tile_weights VALUES (the d_weights / h_weights outputs and the weight rows of a vet_result; calculate_tile_weights and
+ * the accumulation of compute_spatial_entropy, utilities/entropy_utils.py:131-136, 190-192).  Whatever formulation
+ * produces the entropy, they are the reference's: exact FP64 weights, summed over the users in column order, by a
+ * weights-only pass of the `precise` sweep — only calls that ask for the weights pay for it (config-3 shape: ~37 ms for
+ * all 30 000 frames; a vet_result computes the rows of a fetched block, 256 frames ~0.4 ms), and the entropy path is
+ * untouched.  on != 0 returns the formulation's own histogram instead (block-floating-point / FP32 / 2^-52 fixed-point
+ * weight sums: at most n_users * 2^-33 of the row's scale off under the table): a diagnostic for the table layouts. */
+int vet_plan_set_raw_weights(vet_plan *plan, int on);
 int vet_plan_table_stride(const vet_plan *plan, int lattice);
 /* rows of a weight table = distinct directions up to the lattice's mirror symmetry (0 before the first table exists):
  * a table takes (rows + 1) * stride * 6 bytes */
@@ -172,8 +183,9 @@ int vet_plan_read_nearest(vet_plan *plan, int lattice, int32_t *h_nearest /* [n_
  *   d_entropy [T]      mean over the plan's lattices of the normalised spatial entropy
  *   d_assign  [T*U]    nearest tile of lattice 0 per sample, -1 absent      (nullable)
  *   d_weights [T*n_0]  per-frame tile weight sums of lattice 0              (nullable)
+ *                      at the reference's precision under every formulation (vet_plan_set_raw_weights);
  *                      -0.0 = the tile is a key of the reference's dict with the value 0.0 (in some
- *                      user's FoV, weight underflowed), +0.0 = no key        (`precise` rows only)
+ *                      user's FoV, weight underflowed), +0.0 = no key
  *   d_present [T]      users present per frame                              (nullable)
  *   d_status  [2]      {#samples outside [0,1], #frames without a user}; the call ADDS to
  *                      it, the caller zeroes it                             (nullable)   */
@@ -249,6 +261,8 @@ int vet_transition_entropy_host(vet_plan *plan, const double *h_mu, const double
  * entropy only, :216-219).  These variants bring back the entropy series (and the per-frame user counts)
  * and keep assign [T][U] i32 + weights [T][n_0] f64 (transition: pairs [(T-1)][U][2] i32 + srccount
  * [(T-1)][n_0] i32) in device memory owned by a vet_result, from which rows are fetched on demand.
+ * Weighted spatial results hold the samples' direction ids [T][U] i32 instead of the weights and compute the weight
+ * rows of a fetched block when it is fetched (vet_plan_set_raw_weights: the reference's values, off the hot path).
  * A result handle is returned also with VET_ERR_RANGE / VET_ERR_EMPTY. */
 typedef struct vet_result vet_result;
 int vet_spatial_entropy_host_resident(vet_plan *plan, const double *h_mu, const double *h_mv,

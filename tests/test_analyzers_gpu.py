@@ -10,6 +10,7 @@ from viewport_entropy_toolkit.utilities import (calculate_tile_weights, compute_
                                                 compute_transition_entropy, find_nearest_tile,
                                                 generate_fibonacci_lattice)
 from oracle import vet_oracle as vo
+from tests._tol import W_RTOL, w_atol
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-8
@@ -48,7 +49,7 @@ def test_spatial_run_analysis(tmp_path, golden_dir, tag, tcs, ekw):
         got = dict(res["tile_weights"][int(i)])
         assert set(got) == set(ref)          # exactly the reference's keys, whatever the formulation
         for key, w in ref.items():
-            assert got[key] == pytest.approx(w, rel=1e-8, abs=8 * 2.0 ** -33)
+            assert got[key] == pytest.approx(w, rel=W_RTOL, abs=w_atol(8, ekw.get("power_factor", 2.0)))     # no fixed-point term
     csvs = list((tmp_path / "out").glob("video_t_*.csv"))
     pngs = list((tmp_path / "out").glob("video_t_*_graph.png"))
     assert len(csvs) == 1 and len(pngs) == 1
@@ -115,7 +116,7 @@ def test_error_conventions(tmp_path, golden_dir):
     cfg = AnalyzerConfig(tile_counts=[50], output_dir=tmp_path / "out")
     tr = vt.TransitionEntropyAnalyzer(cfg)
     tr.process_directory(d)
-    with pytest.raises(ZeroDivisionError):            # reference: rows without a common user
+    with pytest.raises(ZeroDivisionError, match="^division by zero$"):      # reference: rows without a common user
         tr.compute_entropy()
     sp = vt.SpatialEntropyAnalyzer(cfg)
     sp.process_directory(d)
@@ -256,6 +257,23 @@ def test_result_columns_are_fetched_from_the_device_on_access(tmp_path):
         assert dict(df["tile_assignments"][i]) == {names[u]: int(t) for u, t in enumerate(eager["assign"][i]) if t >= 0}
         assert dict(df.iloc[i]["tile_weights"]) == {tiles[t]: float(w) for t, w in enumerate(eager["weights"][i]) if w > 0}
     assert sum(len(r["tile_assignments"]) for _, r in df.iloc[500:520].iterrows()) == int((eager["assign"][500:520] >= 0).sum())
+    # ... and they are the reference's values (entropy_utils.py:131-136, 190-192), not the table's fixed-point sums: the
+    # plan ran the integer table for the entropy (28 000 samples, policy 0 -> sweep here; forced below), the weight rows
+    # of a fetched block come from the weights-only pass of the precise sweep
+    frames = [0, 255, 256, 699]
+    _, _, wref = vo.spatial_series(mu[frames], mv[frames], 100, 200, [50, 100], want_weights=True)
+    for k, i in enumerate(frames):
+        got = dict(df["tile_weights"][i])
+        assert set(got) == {tiles[t] for t in np.nonzero(wref[k] > 0)[0]}
+        for t in np.nonzero(wref[k] > 0)[0]:
+            assert got[tiles[t]] == pytest.approx(wref[k][t], rel=W_RTOL, abs=w_atol(40))
+    plan = an._get_plan()
+    plan.set_table_policy(1)
+    df1 = an.compute_entropy()
+    assert plan.last_formulation(0) == "table"
+    for i in (0, 300, 699):
+        assert dict(df1["tile_weights"][i]) == dict(df["tile_weights"][i])          # same values whatever the formulation
+    plan.set_table_policy(0)
     tr = TransitionEntropyAnalyzer(AnalyzerConfig(tile_counts=[50], output_dir=tmp_path))
     tr.load_arrays(times, mu, mv)
     dt = tr.compute_entropy()

@@ -33,7 +33,7 @@ def test_ctypes_table_matches_header():
     from viewport_entropy_toolkit import _native
     assert sorted(_native.SIGNATURES) == header_functions()
     lib = _native.load_library()
-    assert lib.vet_version() == 130
+    assert lib.vet_version() == 140
     assert [lib.vet_kernel_name(i).decode() for i in range(6)] == \
         ["k_grid_dirs", "k_nearest_lut", "k_spatial", "k_transition", "k_finalize", "k_wtab"]
 

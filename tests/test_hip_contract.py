@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import vet_oracle as vo
+from tests._tol import W_RTOL, w_atol
 
 pytestmark = pytest.mark.gpu
 
@@ -109,9 +110,8 @@ def test_degenerate_lattices(native, engine, tcs, policy, fov, power):
     assert np.array_equal(np.isnan(res["entropy"]), np.isnan(ent)), (res["entropy"][:10], ent[:10])
     ok = ~np.isnan(ent)
     np.testing.assert_allclose(res["entropy"][ok], ent[ok], rtol=1e-6, atol=ATOL)
-    # FP32 table weights: 2^-24 relative each; integer tables: 2^-33 absolute
-    np.testing.assert_allclose(res["weights"], weights, rtol=1e-7 if plan.last_formulation(0) == "ftable" else 1e-9,
-                               atol=2.0 ** -33 * U)
+    # tile_weights values: the reference's under every formulation (tests/_tol.py)
+    np.testing.assert_allclose(res["weights"], weights, rtol=W_RTOL, atol=w_atol(U, power))
     plan.close()
 
 
@@ -145,7 +145,7 @@ def test_config4_shape(native, engine, policy):
     ent, assign, weights = vo.spatial_series(mu[frames], mv[frames], W, H, tcs, want_weights=True)
     assert np.array_equal(a["assign"][frames], assign)
     np.testing.assert_allclose(a["entropy"][frames], ent, rtol=1e-8)
-    np.testing.assert_allclose(a["weights"][frames], weights, rtol=1e-9, atol=2.0 ** -33 * U + 1e-12)
+    np.testing.assert_allclose(a["weights"][frames], weights, rtol=W_RTOL, atol=w_atol(U))
     plan.close()
 
 

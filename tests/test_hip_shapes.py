@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import vet_oracle as vo
+from tests._tol import W_RTOL, w_atol
 
 pytestmark = pytest.mark.gpu
 
@@ -63,7 +64,7 @@ def test_spatial_shapes(native, engine, U, T, tcs, weighted, policy):
     assert np.array_equal(res["assign"], assign)
     assert np.array_equal(res["present"], (~np.isnan(mu)).sum(1))
     np.testing.assert_allclose(res["entropy"], ent, rtol=1e-8, equal_nan=True)
-    np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=2.0 ** -33 * U + 1e-12)
+    np.testing.assert_allclose(res["weights"], weights, rtol=W_RTOL, atol=w_atol(U))
     plan.close()
 
 
@@ -156,6 +157,87 @@ def test_transition_many_users_lds_ranges(native, engine, U, T, tc, kind):
     plan.close()
 
 
+def test_transition_big_srccount_when_bucket_bound_is_a_multiple_of_cap(native, engine):
+    """k_transition_big cuts a row's source tiles into ranges of bucket bound cap = 8192 * 6 / 10 - n.  When the row's
+    bound sum min(m, n) is a non-zero exact multiple of cap, the empty tiles behind the last populated one belong to no
+    range: their srccount must still be written (0), whatever the pooled output buffer held before."""
+    tc, W, H = 200, 100, 200
+    n = 2 * (tc // 2) + 1
+    cap = 8192 * 6 // 10 - n
+    tiles = vo.fibonacci_lattice(tc)
+    near = vo.nearest_tile(vo.direction_grid(W, H).reshape(-1, 3), tiles)           # [(H+1)(W+1)]
+    # one pixel per source tile for the first tiles of the lattice; the last tiles of the lattice stay empty
+    pix = {}
+    for d, t in enumerate(near):
+        pix.setdefault(int(t), d)
+    full, rest = divmod(cap, n)
+    src_tiles = [t for t in sorted(pix) if t < n - 20][: full + 1]
+    assert len(src_tiles) == full + 1
+    counts = [n] * full + [rest]
+    U, T = 5000, 3
+    assert sum(counts) == cap and cap < U
+    mu = np.full((T, U), np.nan)
+    mv = np.full((T, U), np.nan)
+    u = 0
+    for t, m in zip(src_tiles, counts):
+        d = pix[t]
+        px, py = d % (W + 1), d // (W + 1)
+        mu[:, u:u + m] = min((px + 0.25) / W, 1.0)
+        mv[:, u:u + m] = min((py + 0.25) / H, 1.0)
+        u += m
+    plan = plan_for(native, engine, [tc])
+    # dirty the pooled srccount buffer first: every tile populated
+    rng = np.random.default_rng(5)
+    dirty_mu = rng.random((T, U))
+    dirty_mv = np.clip(np.arccos(1.0 - 2.0 * rng.random((T, U))) / np.pi, 0.0, 1.0)
+    dirty = plan.transition(mu=dirty_mu, mv=dirty_mv, want_srccount=True)
+    assert (dirty["srccount"] > 0).all()
+    res = plan.transition(mu=mu, mv=mv, want_srccount=True)
+    ent, pairs = vo.transition_series(mu, mv, W, H, [tc], closed_form=False)
+    assert np.array_equal(res["pairs"], pairs)
+    src = np.stack([np.bincount(pairs[r][pairs[r][:, 0] >= 0, 0], minlength=n) for r in range(T - 1)])
+    assert src.sum(axis=1).tolist() == [cap] * (T - 1) and (src[:, -20:] == 0).all()
+    assert np.minimum(src, n).sum(axis=1).tolist() == [cap] * (T - 1)
+    assert np.array_equal(res["srccount"], src)
+    np.testing.assert_allclose(res["entropy"], ent, rtol=1e-9, equal_nan=True)
+    plan.close()
+
+
+@pytest.mark.parametrize("policy", [1, -1])
+def test_weight_rows_of_a_resident_result(native, engine, policy):
+    """Weighted spatial results keep the samples' direction ids and compute the weight rows of a fetched block by the
+    weights-only pass of the precise sweep: same bits as the eager weights output, any block boundaries, also after the
+    plan has been destroyed (the result shares the plan's direction table and lattice-0 tiles); (mu, mv) and ids input."""
+    mu, mv = video(70, 90, seed=12)
+    plan = plan_for(native, engine, [100, 20], policy=policy)
+    eager = plan.spatial(mu=mu, mv=mv, want_weights=True)
+    lazy = plan.spatial_resident(mu=mu, mv=mv)
+    assert np.array_equal(lazy["entropy"], eager["entropy"], equal_nan=True)
+    _, _, weights = vo.spatial_series(mu, mv, 100, 200, [100, 20], want_weights=True)
+    np.testing.assert_allclose(eager["weights"], weights, rtol=W_RTOL, atol=w_atol(70))
+    plan.close()
+    res = lazy["result"]
+    assert np.array_equal(res.rows(1, 0, 90), eager["weights"])
+    assert np.array_equal(res.rows(1, 37, 5), eager["weights"][37:42])
+    assert np.array_equal(res.rows(1, 89, 1), eager["weights"][89:])
+    assert np.array_equal(res.rows(0, 0, 90), eager["assign"])
+    res.close()
+    # explicit direction table (the operator boundary's *_ids entry points)
+    rng = np.random.default_rng(3)
+    table = vo.vector_from_spherical(np.round(rng.uniform(-180, 180, 200), 1), np.round(rng.uniform(-90, 90, 200), 1))
+    ids = rng.integers(-1, 200, (30, 17)).astype(np.int32)
+    ids[:, 0] = np.abs(ids[:, 0])
+    plan = native.Plan(engine, [vo.fibonacci_lattice(50)], 120.0, 2.0, True, dir_table=table)
+    plan.set_table_policy(policy)
+    eager = plan.spatial(ids=ids, want_weights=True)
+    lazy = plan.spatial_resident(ids=ids)
+    plan.close()
+    assert np.array_equal(lazy["result"].rows(1, 3, 20), eager["weights"][3:23])
+    for t in (0, 29):
+        _, hist, _ = vo.spatial_entropy_frame(table[ids[t][ids[t] >= 0]], vo.fibonacci_lattice(50))
+        np.testing.assert_allclose(eager["weights"][t], hist, rtol=W_RTOL, atol=w_atol(17))
+
+
 def test_heavily_clustered_users(native, engine):
     """Everybody looks at the same few tiles: same-address LDS atomics, buckets with many users."""
     rng = np.random.default_rng(1)
@@ -201,9 +283,8 @@ def test_extreme_entropy_configs(native, engine, fov, power, policy):
     ent, assign, weights = vo.spatial_series(mu, mv, 100, 200, [100, 20], fov_angle=fov, power_factor=power,
                                              want_weights=True)
     assert np.array_equal(res["assign"], assign)
-    # the table stores 32-bit mantissas below the row's largest weight: at most 2^-32 absolute per weight
-    np.testing.assert_allclose(res["weights"], weights, rtol=1e-7 if plan.last_formulation(0) == "ftable" else 1e-9,
-                               atol=2.0 ** -32 * 60 + 1e-12)
+    # tile_weights values are the reference's whatever the formulation (tests/_tol.py)
+    np.testing.assert_allclose(res["weights"], weights, rtol=W_RTOL, atol=w_atol(60, power))
     assert np.array_equal(np.isnan(res["entropy"]), np.isnan(ent))
     ok = np.isfinite(ent)
     fp = "ftable" in (plan.last_formulation(0), plan.last_formulation(1))       # FP32 table weights: |dH|/H <= 1.2e-7
@@ -244,7 +325,7 @@ def test_very_large_lattice(native, engine, policy):
     ent, assign, weights = vo.spatial_series(mu, mv, 100, 200, [5000], want_weights=True)
     assert np.array_equal(res["assign"], assign)
     np.testing.assert_allclose(res["entropy"], ent, rtol=1e-8)
-    np.testing.assert_allclose(res["weights"], weights, rtol=1e-9, atol=2.0 ** -32 * 50 + 1e-12)
+    np.testing.assert_allclose(res["weights"], weights, rtol=W_RTOL, atol=w_atol(50))
     tr = plan.transition(mu=mu, mv=mv)
     e2, pairs = vo.transition_series(mu, mv, 100, 200, [5000])
     assert np.array_equal(tr["pairs"], pairs)
@@ -301,6 +382,7 @@ def _fused_variants_worker(q, env):
         mu, mv = _synthetic.random_walk_video(U, T, base_seed=17, p_absent=0.1)
         plan = _native.Plan(eng, [vo.fibonacci_lattice(tc) for tc in tcs], 120.0, 2.0, True, 100, 200)
         plan.set_table_policy(1)
+        plan.set_raw_weights(True)               # the tables' own histograms are what the variants are compared on
         r = plan.spatial(mu=mu, mv=mv, want_weights=True)
         out[name] = (r["entropy"], r["assign"], r["weights"], plan.last_formulation(0))
         plan.close()

@@ -37,14 +37,16 @@ def keys_of(weights):
     return (weights != 0) | np.signbit(weights)
 
 
+@pytest.mark.parametrize("raw", [pytest.param(False, id="weights-pass"), pytest.param(True, id="own-histogram")])
 @pytest.mark.parametrize("policy", [1, -1, 0])
 @pytest.mark.parametrize("tc,fov,power", CONFIGS)
-def test_g12_nan_pattern_and_keys(native, engine, golden_dir, tc, fov, power, policy):
+def test_g12_nan_pattern_and_keys(native, engine, golden_dir, tc, fov, power, policy, raw):
     g = np.load(golden_dir / "g12_underflow.npz")
     tag = f"tc{tc}_fov{fov}_p{power}"
     mu, mv = samples(g["px"], g["py"])
     plan = native.Plan(engine, [vo.fibonacci_lattice(tc)], float(fov), float(power), True, W, H)
     plan.set_table_policy(policy)
+    plan.set_raw_weights(raw)
     tab_bound, sweep_bound = plan.error_bounds(0)
     res = plan.spatial(mu=mu, mv=mv, want_weights=True)
     form = plan.last_formulation(0)
@@ -56,7 +58,11 @@ def test_g12_nan_pattern_and_keys(native, engine, golden_dir, tc, fov, power, po
     assert np.array_equal(np.isnan(res["entropy"]), np.isnan(ref)), (form, np.flatnonzero(np.isnan(res["entropy"]) != np.isnan(ref)))
     ok = ~np.isnan(ref)
     np.testing.assert_allclose(res["entropy"][ok], ref[ok], rtol=1e-6, atol=1e-15)
-    if form in ("ftable", "precise"):                  # the FP64 formulations keep the reference's key set exactly
+    if not raw:
+        # the weights output proper: the reference's keys and values (subnormal weights included) under every formulation
+        assert np.array_equal(keys_of(res["weights"]), g[f"{tag}__keys"]), form
+        np.testing.assert_allclose(np.abs(res["weights"]), g[f"{tag}__hist"], rtol=1e-9, atol=0)
+    elif form in ("ftable", "precise"):                # the FP64 formulations keep the reference's key set exactly
         assert np.array_equal(keys_of(res["weights"]), g[f"{tag}__keys"]), form
         np.testing.assert_allclose(np.abs(res["weights"]), g[f"{tag}__hist"], rtol=2e-7 if form == "ftable" else 1e-9,
                                    atol=8 * 2.0 ** -149 if form == "ftable" else 0)     # FP32 entries below 2^-126 of their row's scale are denormal
@@ -67,8 +73,9 @@ def test_g12_nan_pattern_and_keys(native, engine, golden_dir, tc, fov, power, po
 
 @pytest.mark.parametrize("tcs,fov,power,U", [([500], 120.0, 150.0, 160), ([50, 500], 120.0, 100.0, 160), ([50, 500], 60.0, 200.0, 48),
                                              ([500, 50], 120.0, 80.0, 200)])
+@pytest.mark.parametrize("raw", [pytest.param(False, id="weights-pass"), pytest.param(True, id="own-histogram")])
 @pytest.mark.parametrize("policy", [1, -1])
-def test_resolver_on_crowded_frames(native, engine, tcs, fov, power, U, policy):
+def test_resolver_on_crowded_frames(native, engine, tcs, fov, power, U, policy, raw):
     """Frames of many users (the table kernel's set of distinct rows, fused lattices): the frames the marker
     entries cannot decide go through the precise sweep inside the call and come back as the oracle has them."""
     rng = np.random.default_rng(int(power) + U)
@@ -83,6 +90,7 @@ def test_resolver_on_crowded_frames(native, engine, tcs, fov, power, U, policy):
     mu, mv = samples(px, py)
     plan = native.Plan(engine, [vo.fibonacci_lattice(tc) for tc in tcs], fov, power, True, W, H)
     plan.set_table_policy(policy)
+    plan.set_raw_weights(raw)
     a = plan.spatial(mu=mu, mv=mv, want_weights=True)
     assert plan.last_formulation(0) == ("ftable" if policy > 0 else "precise")
     b = plan.spatial(mu=mu, mv=mv, want_weights=False, want_assign=False)
@@ -93,7 +101,8 @@ def test_resolver_on_crowded_frames(native, engine, tcs, fov, power, U, policy):
     ok = ~np.isnan(ent)
     np.testing.assert_allclose(a["entropy"][ok], ent[ok], rtol=1e-6, atol=1e-15)
     assert np.array_equal(keys_of(a["weights"]), keys_of(weights))
-    np.testing.assert_allclose(np.abs(a["weights"]), np.abs(weights), rtol=2e-7 if policy > 0 else 1e-9, atol=U * 2.0 ** -149 if policy > 0 else 0)
+    fp32 = raw and policy > 0                      # the FP table's own histogram: FP32 entries; otherwise the reference's values
+    np.testing.assert_allclose(np.abs(a["weights"]), np.abs(weights), rtol=2e-7 if fp32 else 1e-9, atol=U * 2.0 ** -149 if fp32 else 0)
     plan.close()
 
 

@@ -272,7 +272,8 @@ def test_transition_empty_row_error_mapping():
     assert isinstance(e, vt.ValidationError) and str(e) == "Empty vector dictionary"
     # both frames populated, disjoint users
     mu = np.array([[0.1, nan], [nan, 0.2], [0.3, 0.4]])
-    assert isinstance(TA._empty_row_error("grid", mu, mu.copy()), ZeroDivisionError)
+    err = TA._empty_row_error("grid", mu, mu.copy())
+    assert isinstance(err, ZeroDivisionError) and str(err) == "division by zero"     # int 0 (entropy_utils.py:326)
     # the first failing pair decides: rows 0->1 disjoint (ZeroDivisionError) before the empty frame 2
     mu = np.array([[0.1, nan], [nan, 0.2], [nan, nan]])
     assert isinstance(TA._empty_row_error("grid", mu, mu.copy()), ZeroDivisionError)

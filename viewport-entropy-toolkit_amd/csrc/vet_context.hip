@@ -14,7 +14,7 @@ namespace vh {
 namespace {
 thread_local std::string g_err;
 const char* const kKernelNames[KID_COUNT] = {"k_grid_dirs", "k_nearest_lut", "k_spatial", "k_transition",
-                                             "k_finalize", "k_wtab"};
+                                             "k_finalize", "k_wtab", "k_weights"};
 
 // a value outside [lo, hi] (or not a number) is ignored
 int env_int(const char* name, int lo, int hi, int fallback) {
@@ -58,6 +58,9 @@ void Tuning::from_environment() {
     u_fpw = env_int("VET_U_FPW", 1, 64, 0);
     u_waves = env_int("VET_U_WAVES", 1, 16, 4);
     t_threads = env_threads("VET_T_THREADS", 0);
+    // powers of two only: the launch logic doubles the workgroup until it covers the users (192 -> 1536 would exceed 1024
+    // threads and the 16 wave slots of the cell sums)
+    if (t_threads & (t_threads - 1)) t_threads = 0;
     t_wgs_per_cu = env_int("VET_T_WGS_PER_CU", 1, 16, 0);
     t_global = env_flag("VET_T_GLOBAL");
     t_hs_pct = env_int("VET_T_HS_PCT", 100, 400, 200);     // bucket-hash slots per 100 users (100: no gain, 43.3 vs 43.7 us)
@@ -109,6 +112,39 @@ int pooled(vet_ctx* c, int slot, size_t bytes, void** out) {
     }
     *out = c->pool[slot];
     return VET_OK;
+}
+
+int BatchBlob::acquire(vet_ctx* ctx, size_t nbytes) {
+    c = ctx; bytes = nbytes ? nbytes : 8;
+    BatchStage& t = c->stage[c->stage_next];
+    c->stage_next = (c->stage_next + 1) % kBatchStages;
+    if (t.pending) {                                       // the batch that used this slot kBatchStages calls ago
+        HIP_TRY(hipEventSynchronize(t.done));
+        t.pending = false;
+    }
+    if (!t.done) HIP_TRY(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+    if (t.cap < bytes) {
+        if (t.h) { HIP_TRY(hipHostFree(t.h)); t.h = nullptr; }
+        if (t.d) { HIP_TRY(hipFree(t.d)); t.d = nullptr; }
+        t.cap = 0;
+        const size_t want = bytes + bytes / 8;
+        HIP_TRY(hipHostMalloc(&t.h, want, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&t.d, want));
+        t.cap = want;
+    }
+    st = &t;
+    return VET_OK;
+}
+
+int BatchBlob::upload(hipStream_t stream) {
+    s = stream;
+    uploaded = true;                                       // from here on the slot is in flight, whatever follows
+    HIP_TRY(hipMemcpyAsync(st->d, st->h, bytes, hipMemcpyHostToDevice, s));
+    return VET_OK;
+}
+
+BatchBlob::~BatchBlob() {
+    if (st && uploaded && hipEventRecord(st->done, s) == hipSuccess) st->pending = true;
 }
 
 int grid_for(long work, int block, int n_cu) {
@@ -184,6 +220,11 @@ int vet_destroy(vet_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->d_log2) (void)hipFree(c->d_log2);
     for (void* q : c->pool) if (q) (void)hipFree(q);
+    for (auto& t : c->stage) {
+        if (t.h) (void)hipHostFree(t.h);
+        if (t.d) (void)hipFree(t.d);
+        if (t.done) (void)hipEventDestroy(t.done);
+    }
     (void)hipStreamDestroy(c->stream);
     delete c;
     return VET_OK;

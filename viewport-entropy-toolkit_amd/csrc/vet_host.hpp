@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -36,12 +37,37 @@ struct DevBuf {
     hipError_t alloc(size_t b) { return hipMalloc(&p, b ? b : 8); }
 };
 
-enum { KID_GRID = 0, KID_NEAREST = 1, KID_SPATIAL = 2, KID_TRANSITION = 3, KID_FINALIZE = 4, KID_WTAB = 5, KID_COUNT = 6 };
+enum { KID_GRID = 0, KID_NEAREST = 1, KID_SPATIAL = 2, KID_TRANSITION = 3, KID_FINALIZE = 4, KID_WTAB = 5, KID_WEIGHTS = 6, KID_COUNT = 7 };
 
 struct EventPair {
     int kid;
     hipEvent_t a, b;
 };
+
+// What the weights-only pass of the precise sweep needs of a plan (tile_weights VALUES at the reference's precision:
+// exact FP64 weights summed in the reference's column order, calculate_tile_weights / compute_spatial_entropy,
+// utilities/entropy_utils.py:108-144, 179-192).  The two device tables are shared with the plan, so a device-resident
+// result (vet_result) that recomputes its weight rows on fetch may outlive the plan and its context.
+struct WeightsCore {
+    int device = 0;
+    size_t lds_max = 64 * 1024;
+    int n_cu = 256;
+    std::shared_ptr<void> dir_unit;    // [n_dirs][3] f64 unit directions
+    std::shared_ptr<void> tiles0;      // [n0][3] f64 unit tile centres of lattice 0
+    int n0 = 0;
+    int64_t n_dirs = 0;
+    double cos_cull = 0.0, max_ang = 0.0, power = 2.0;
+};
+
+// One slot of the batch-descriptor ring (vet_ctx::stage)
+struct BatchStage {
+    void* h = nullptr;          // pinned host copy
+    void* d = nullptr;          // device copy
+    size_t cap = 0;
+    hipEvent_t done = nullptr;  // recorded behind the last launch that reads d
+    bool pending = false;
+};
+constexpr int kBatchStages = 4;
 
 // Tuning knobs.  The environment is read ONCE, in vet_create; nothing between a C-ABI entry point and
 // its kernel launches calls getenv.  A value outside its range is ignored (the built-in default stays).
@@ -82,12 +108,15 @@ struct vet_ctx {
     size_t ws_bytes = 0;
     double* d_log2 = nullptr;      // log2(k), k = 0..4096
     bool attrs_set = false;        // dynamic-LDS limits of the run kernels raised (first plan)
-    // grow-only device staging buffers (no hipMalloc per call): 0-6 host-buffer entry points, 7 batch descriptors,
+    // grow-only device staging buffers (no hipMalloc per call): 0-6 host-buffer entry points, (7 unused: batch descriptors live in the blob ring below),
     // 8 transition scratch, 9 resolve list
     void* pool[12] = {};
     size_t pool_cap[12] = {};
-    // host copies of the last batch's descriptors: they must outlive the asynchronous copies that read them
-    std::vector<unsigned char> batch_host;
+    // descriptor blobs of the batch entry points: a ring of (pinned host, device) buffer pairs, each guarded by an event
+    // recorded behind the last launch that reads it (vh::BatchBlob) — the calls only enqueue work, so neither the host
+    // copy nor the device copy of one batch may be reused while an earlier batch (possibly on another stream) is pending
+    vh::BatchStage stage[vh::kBatchStages];
+    int stage_next = 0;
     // profiling
     bool profiling = false;
     std::vector<vh::EventPair> pending;
@@ -141,6 +170,7 @@ struct vet_plan {
     int weighted = 1;
     double cos_cull = 0.0;
     int table_policy = 0;          // 0 by call size, 1 table whenever it is inside the contract, -1 never
+    bool raw_weights = false;      // tile_weights = the formulation's own histogram (diagnostic) instead of the exact pass
     uint32_t* d_alias = nullptr;   // [n_dirs] direction id -> table row (dense) | mirrored << 31 (ensure_alias)
     bool mirror = false;           // rows are shared between mirror-image directions
     uint2* d_dirrec = nullptr;     // [n_dirs] alias | nearest tile | lattice-0 row meta (k_dirrec), dedup-capable plans
@@ -159,6 +189,7 @@ struct vet_plan {
         uint32_t* d_w = nullptr;   // [R+1][stride]
         uint16_t* d_i = nullptr;   // [R+1][stride]
     } fused;
+    vh::WeightsCore wcore;         // owner of d_dir_unit and lat[0].d_tiles (shared with device-resident results)
     bool stats_all = false;        // k_row_stats has run for every weighted lattice
     bool ultra = false;            // some lattice has ultra-tiny in-FoV weights: FP64 formulations only (plan-wide)
 };
@@ -189,6 +220,22 @@ struct ProfScope {
     }
 };
 
+// The descriptor blob of ONE batch call: acquire() takes the ring's next slot (waiting only if the batch that used it
+// kBatchStages calls ago has not finished), the caller fills host(), upload() enqueues the copy, the launches follow, and
+// the destructor records the slot's event on the launch stream.
+struct BatchBlob {
+    vet_ctx* c = nullptr;
+    BatchStage* st = nullptr;
+    hipStream_t s = nullptr;
+    size_t bytes = 0;
+    bool uploaded = false;
+    int acquire(vet_ctx* ctx, size_t nbytes);
+    void* host() const { return st->h; }
+    void* dev() const { return st->d; }
+    int upload(hipStream_t stream);
+    ~BatchBlob();
+};
+
 int ensure_ws(vet_ctx* c, size_t bytes);                          // grow-only workspace (c->ws)
 int pooled(vet_ctx* c, int slot, size_t bytes, void** out);       // slot-indexed grow-only device buffer
 int grid_for(long work, int block, int n_cu);
@@ -204,6 +251,12 @@ int ensure_all_stats(vet_plan* pl, hipStream_t s);
 int ensure_wtab(vet_plan* pl, int k, hipStream_t s);
 int ensure_fused(vet_plan* pl, hipStream_t s);
 bool any_binned(const vet_plan* pl);
+
+// vet_spatial.hip: tile_weights of lattice 0 for frames [0, T) of a sample array given as direction ids, by the precise
+// sweep in weights-only mode (users in column order); prof = context to attribute the launch to, or null
+int weights_pass_ids(const WeightsCore& w, const int32_t* d_ids, int U, int T, double* d_weights, hipStream_t s, vet_ctx* prof);
+// (mu, mv) -> direction ids [n] (-1 absent or out of range) on the plan's pixel grid
+int sample_ids(const vet_plan* pl, const double* d_mu, const double* d_mv, long n, int32_t* d_out, hipStream_t s);
 
 // dynamic-LDS limits of the run kernels (once per context, from vet_plan_create)
 int spatial_set_attrs(vet_ctx* c);

@@ -13,9 +13,19 @@ extern "C" {
 
 struct vet_result {
     int device = 0;                      // the result may outlive its context: only the device id is kept
-    void* d[2] = {nullptr, nullptr};     // 0: assign / pairs, 1: weights / srccount
+    void* d[2] = {nullptr, nullptr};     // 0: assign / pairs, 1: weights / srccount (null when the weights are lazy)
     size_t row_bytes[2] = {0, 0};
     int64_t rows = 0;
+    // Weighted spatial results do not store tile_weights: they keep the samples' direction ids [T][U] and the plan's
+    // shared tables, and a fetched block of weight rows is computed by the weights-only pass of the precise sweep —
+    // the reference's values (exact weights, column order) whatever formulation produced the entropy, and 120 MB less
+    // to write on the hot path of BASELINE config 3.
+    bool lazy_weights = false;
+    WeightsCore core;
+    int32_t* d_ids = nullptr;
+    int U = 0;
+    void* d_tmp = nullptr;               // grow-only staging of the fetched weight rows
+    size_t tmp_cap = 0;
 };
 
 static int run_host(vet_plan* pl, bool transition, const double* h_mu, const double* h_mv, const int32_t* h_ids,
@@ -54,7 +64,15 @@ static int run_host(vet_plan* pl, bool transition, const double* h_mu, const dou
         res->rows = R > 0 ? R : 0;
         res->row_bytes[0] = transition ? (size_t)U * 2 * 4 : (size_t)U * 4;
         res->row_bytes[1] = transition ? (size_t)n0 * 4 : (size_t)n0 * 8;
-        if (hipMalloc(&res->d[0], a_bytes ? a_bytes : 8) != hipSuccess || hipMalloc(&res->d[1], b_bytes ? b_bytes : 8) != hipSuccess) {
+        res->lazy_weights = !transition && pl->weighted && !pl->lat[0].binned && !pl->raw_weights;
+        bool ok = hipMalloc(&res->d[0], a_bytes ? a_bytes : 8) == hipSuccess;
+        if (ok && res->lazy_weights) {
+            res->core = pl->wcore; res->U = U;
+            ok = hipMalloc((void**)&res->d_ids, S * 4 ? S * 4 : 8) == hipSuccess;
+        } else if (ok) {
+            ok = hipMalloc(&res->d[1], b_bytes ? b_bytes : 8) == hipSuccess;
+        }
+        if (!ok) {
             (void)hipGetLastError();
             vet_result_free(res);
             return fail(VET_ERR_DEVICE, "out of device memory for the resident outputs (%zu B)", a_bytes + b_bytes);
@@ -80,6 +98,14 @@ static int run_host(vet_plan* pl, bool transition, const double* h_mu, const dou
                                        (double*)b, (int32_t*)cc, (int32_t*)st, s);
     }
     if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    if (res && res->lazy_weights) {
+        // the direction ids the weight rows are recomputed from on fetch
+        if (ids) HIP_TRY(hipMemcpyAsync(res->d_ids, id, S * 4, hipMemcpyDeviceToDevice, s));
+        else {
+            rc = sample_ids(pl, (const double*)mu, (const double*)mv, (long)S, res->d_ids, s);
+            if (rc) { (void)hipStreamSynchronize(s); return rc; }
+        }
+    }
     int32_t status[2] = {0, 0};
     if (R > 0) {
         HIP_TRY(hipMemcpyAsync(h_entropy, ent, (size_t)R * 8, hipMemcpyDeviceToHost, s));
@@ -117,6 +143,20 @@ int vet_result_fetch(vet_result* r, int which, int64_t row0, int64_t n_rows, voi
                     (long long)(row0 + n_rows), (long long)r->rows);
     if (n_rows == 0) return VET_OK;
     HIP_TRY(hipSetDevice(r->device));
+    if (which == 1 && r->lazy_weights) {
+        // tile_weights rows [row0, row0 + n_rows): computed now, from the resident direction ids (null stream: the
+        // call that made the result has synchronised its stream, and the result may have outlived its context)
+        const size_t bytes = (size_t)n_rows * r->row_bytes[1];
+        if (r->tmp_cap < bytes) {
+            if (r->d_tmp) { HIP_TRY(hipFree(r->d_tmp)); r->d_tmp = nullptr; r->tmp_cap = 0; }
+            HIP_TRY(hipMalloc(&r->d_tmp, bytes));
+            r->tmp_cap = bytes;
+        }
+        int rc = weights_pass_ids(r->core, r->d_ids + (size_t)row0 * r->U, r->U, (int)n_rows, (double*)r->d_tmp, nullptr, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(h_dst, r->d_tmp, bytes, hipMemcpyDeviceToHost));
+        return VET_OK;
+    }
     HIP_TRY(hipMemcpy(h_dst, (const char*)r->d[which] + (size_t)row0 * r->row_bytes[which], (size_t)n_rows * r->row_bytes[which],
                       hipMemcpyDeviceToHost));
     return VET_OK;
@@ -126,6 +166,8 @@ int vet_result_free(vet_result* r) {
     if (!r) return VET_OK;
     (void)hipSetDevice(r->device);
     for (void* q : r->d) if (q) (void)hipFree(q);
+    if (r->d_ids) (void)hipFree(r->d_ids);
+    if (r->d_tmp) (void)hipFree(r->d_tmp);
     delete r;
     return VET_OK;
 }

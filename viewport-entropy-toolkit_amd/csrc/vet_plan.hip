@@ -500,6 +500,15 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
         c->attrs_set = true;
     }
 #undef PLAN_TRY
+    {   // the weights-only pass (vet_host.hpp: WeightsCore) shares the direction table and lattice 0's tiles
+        auto dev_free = [](void* q) { if (q) (void)hipFree(q); };
+        vh::WeightsCore& w = pl->wcore;
+        w.device = c->device; w.lds_max = c->lds_max; w.n_cu = c->n_cu;
+        w.dir_unit = std::shared_ptr<void>((void*)pl->d_dir_unit, dev_free);
+        if (pl->lat[0].d_tiles) w.tiles0 = std::shared_ptr<void>((void*)pl->lat[0].d_tiles, dev_free);
+        w.n0 = pl->lat[0].n; w.n_dirs = pl->n_dirs;
+        w.cos_cull = pl->cos_cull; w.max_ang = pl->max_ang; w.power = pl->power;
+    }
     *out = pl;
     return VET_OK;
 }
@@ -509,9 +518,10 @@ int vet_plan_destroy(vet_plan* pl) {
     (void)hipSetDevice(pl->ctx->device);
     (void)hipStreamSynchronize(pl->ctx->stream);
     if (pl->d_dir_raw) (void)hipFree(pl->d_dir_raw);
-    if (pl->d_dir_unit) (void)hipFree(pl->d_dir_unit);
+    // d_dir_unit and lat[0].d_tiles belong to pl->wcore once the plan is complete (shared with device-resident results)
+    if (pl->d_dir_unit && !pl->wcore.dir_unit) (void)hipFree(pl->d_dir_unit);
     for (auto& L : pl->lat) {
-        if (L.d_tiles) (void)hipFree(L.d_tiles);
+        if (L.d_tiles && !(&L == &pl->lat[0] && pl->wcore.tiles0)) (void)hipFree(L.d_tiles);
         if (L.d_nearest) (void)hipFree(L.d_nearest);
         if (L.d_tab_w) (void)hipFree(L.d_tab_w);
         if (L.d_tab_i) (void)hipFree(L.d_tab_i);
@@ -536,6 +546,12 @@ int64_t vet_plan_n_dirs(const vet_plan* pl) { return pl ? pl->n_dirs : 0; }
 int vet_plan_set_table_policy(vet_plan* pl, int policy) {
     if (!pl) return fail(VET_ERR_INVALID, "plan is NULL");
     pl->table_policy = policy > 0 ? 1 : (policy < 0 ? -1 : 0);
+    return VET_OK;
+}
+
+int vet_plan_set_raw_weights(vet_plan* pl, int on) {
+    if (!pl) return fail(VET_ERR_INVALID, "plan is NULL");
+    pl->raw_weights = on != 0;
     return VET_OK;
 }
 

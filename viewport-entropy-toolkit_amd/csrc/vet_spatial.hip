@@ -20,6 +20,29 @@ struct Geometry {
     size_t lds;
 };
 
+// launch geometry of the weighted sweep kernels (k_spatial_w) for a lattice of n tiles and U users
+int sweep_geometry(size_t lds_max, int n, int U, Geometry* g, bool one_frame = false) {
+    g->R = n > vet::WAVE ? 2 : 1;
+    g->G = (n + vet::WAVE * g->R - 1) / (vet::WAVE * g->R);
+    if (g->G >= 4) { g->NW = g->G > 16 ? 16 : g->G; g->FPW = 1; }
+    else { g->NW = 4; g->FPW = 4 / g->G; }
+    if (one_frame) g->FPW = 1;
+    g->UC = U < 1024 ? U : 1024;
+    auto lds_of = [&](int fpw, int uc) {
+        size_t b = (size_t)fpw * n * 8;
+        b += (size_t)fpw * uc * 24;
+        b += (size_t)g->NW * vet::WAVE * (g->R + 1) * (8 + 2);
+        b += (size_t)2 * fpw * 4 + 64;
+        return b;
+    };
+    while (lds_of(g->FPW, g->UC) > lds_max && g->FPW > 1) g->FPW /= 2;
+    while (lds_of(g->FPW, g->UC) > lds_max && g->UC > 64) g->UC /= 2;
+    g->lds = lds_of(g->FPW, g->UC);
+    if (g->lds > lds_max)
+        return fail(VET_ERR_UNSUPPORTED, "lattice of %d tiles does not fit the LDS histogram (%zu B)", n, g->lds);
+    return VET_OK;
+}
+
 // launch geometry of the spatial kernels for a lattice of n tiles and U users
 int spatial_geometry(const vet_ctx* c, int n, int U, bool weighted, Geometry* g, bool one_frame = false) {
     if (!weighted) {
@@ -34,25 +57,7 @@ int spatial_geometry(const vet_ctx* c, int n, int U, bool weighted, Geometry* g,
             return fail(VET_ERR_UNSUPPORTED, "lattice of %d tiles does not fit the LDS histogram (%zu B)", n, g->lds);
         return VET_OK;
     }
-    g->R = n > vet::WAVE ? 2 : 1;
-    g->G = (n + vet::WAVE * g->R - 1) / (vet::WAVE * g->R);
-    if (g->G >= 4) { g->NW = g->G > 16 ? 16 : g->G; g->FPW = 1; }
-    else { g->NW = 4; g->FPW = 4 / g->G; }
-    if (one_frame) g->FPW = 1;
-    g->UC = U < 1024 ? U : 1024;
-    auto lds_of = [&](int fpw, int uc) {
-        size_t b = (size_t)fpw * n * 8;
-        b += (size_t)fpw * uc * 24;
-        b += (size_t)g->NW * vet::WAVE * (g->R + 1) * (8 + 2);
-        b += (size_t)2 * fpw * 4 + 64;
-        return b;
-    };
-    while (lds_of(g->FPW, g->UC) > c->lds_max && g->FPW > 1) g->FPW /= 2;
-    while (lds_of(g->FPW, g->UC) > c->lds_max && g->UC > 64) g->UC /= 2;
-    g->lds = lds_of(g->FPW, g->UC);
-    if (g->lds > c->lds_max)
-        return fail(VET_ERR_UNSUPPORTED, "lattice of %d tiles does not fit the LDS histogram (%zu B)", n, g->lds);
-    return VET_OK;
+    return sweep_geometry(c->lds_max, n, U, g, one_frame);
 }
 
 // weight-evaluation variant of k_spatial_w (see fov_weight_fx)
@@ -384,9 +389,64 @@ int resolve_frames(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc
     return VET_OK;
 }
 
+// tile_weights of lattice 0, frames [0, T): the precise sweep in weights-only mode (exact ocml weights, FP64 histogram,
+// every tile owned by one wave, users in column order = the reference's own summation order; -0.0 = key with the value 0.0)
+template <bool FROM_IDS>
+int launch_weights_pass(const WeightsCore& w, const vet::SampleSrc& src, int U, int T, double* d_weights, hipStream_t s,
+                        vet_ctx* prof) {
+    if (T <= 0) return VET_OK;
+    Geometry g;
+    int rc = sweep_geometry(w.lds_max, w.n0, U, &g);
+    if (rc) return rc;
+    vet::SpatialParams p{};
+    p.src = src; p.U = U; p.T = T;
+    p.dir_unit = (const double*)w.dir_unit.get(); p.nearest = nullptr; p.tiles = (const double*)w.tiles0.get(); p.n = w.n0;
+    p.cos_cull = w.cos_cull;
+    p.wc.max_ang = w.max_ang; p.wc.inv_max = 1.0 / w.max_ang; p.wc.power = w.power; p.wc.shift = 0;
+    p.hmax = 1.0;
+    p.ent_k = nullptr; p.assign = nullptr; p.present = nullptr; p.status = nullptr;      // weights only
+    p.weights = d_weights;
+    p.FPW = g.FPW; p.G = g.G; p.UC = g.UC;
+    p.norm_n = w.n0; p.frame_list = nullptr;
+    const int blocks = (T + g.FPW - 1) / g.FPW;
+    void* args[] = {(void*)&p};
+    if (prof) {
+        ProfScope ps(prof, s, KID_WEIGHTS);
+        HIP_TRY(hipLaunchKernel(spatial_w_kernel<FROM_IDS>(0, g.R, true), dim3(blocks), dim3(g.NW * vet::WAVE), args, g.lds, s));
+    } else {
+        HIP_TRY(hipLaunchKernel(spatial_w_kernel<FROM_IDS>(0, g.R, true), dim3(blocks), dim3(g.NW * vet::WAVE), args, g.lds, s));
+    }
+    HIP_TRY(hipGetLastError());
+    return VET_OK;
+}
+
+template <bool FROM_IDS>
+int launch_spatial_main(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double* d_entropy, int32_t* d_assign,
+                        double* d_weights, double* d_weights_precise, bool* wrote_precise, int32_t* d_present, int32_t* d_status,
+                        hipStream_t s);
+
+// tile_weights VALUES carry the reference's precision under every formulation (utilities/entropy_utils.py:131-136,
+// 190-192): only the `precise` formulation writes them itself; the table / FP table / integer sweep formulations — whose
+// histograms hold block-floating-point, FP32-rounded or 2^-52 fixed-point weights, good for the ENTROPY contract only —
+// leave the weights output to a weights-only pass of the precise sweep over the same samples (off the hot path: only
+// calls that ask for d_weights pay for it; the drop-in keeps the samples' direction ids and runs it per fetched block).
 template <bool FROM_IDS>
 int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double* d_entropy, int32_t* d_assign,
                    double* d_weights, int32_t* d_present, int32_t* d_status, hipStream_t s) {
+    const bool exact = d_weights && pl->weighted && !pl->lat[0].binned && !pl->raw_weights;
+    bool wrote = false;
+    int rc = launch_spatial_main<FROM_IDS>(pl, src, U, T, d_entropy, d_assign, exact ? nullptr : d_weights,
+                                           exact ? d_weights : nullptr, &wrote, d_present, d_status, s);
+    if (rc || !exact || wrote) return rc;
+    return launch_weights_pass<FROM_IDS>(pl->wcore, src, U, T, d_weights, s, pl->ctx);
+}
+
+// d_weights: written by whatever formulation runs (unweighted / binned plans: integer counts, exact);
+// d_weights_precise: written only if lattice 0 runs the `precise` formulation (*wrote_precise tells)
+template <bool FROM_IDS>
+int launch_spatial_main(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double* d_entropy, int32_t* d_assign,
+                        double* d_weights, double* d_weights_precise, bool* wrote_precise, int32_t* d_present, int32_t* d_status,
+                        hipStream_t s) {
     vet_ctx* c = pl->ctx;
     const int K = (int)pl->lat.size();
     double* ent_k = d_entropy;
@@ -480,6 +540,7 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
         p.ent_k = ent_k + (size_t)k * T;
         p.assign = k == 0 ? d_assign : nullptr;
         p.weights = k == 0 ? d_weights : nullptr;
+        if (k == 0 && precise && d_weights_precise) { p.weights = d_weights_precise; *wrote_precise = true; }
         p.present = k == 0 ? d_present : nullptr;
         p.status = k == 0 ? d_status : nullptr;
         p.FPW = g.FPW; p.G = g.G; p.UC = g.UC;
@@ -535,6 +596,24 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
 }
 
 }  // namespace
+
+__global__ void k_sample_ids(const vet::SampleSrc src, long n, int32_t* __restrict__ out) {
+    bool bad = false;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(vet::sample_dir<false>(src, i, bad), out + i);
+}
+
+int weights_pass_ids(const WeightsCore& w, const int32_t* d_ids, int U, int T, double* d_weights, hipStream_t s, vet_ctx* prof) {
+    const vet::SampleSrc src{nullptr, nullptr, d_ids, 0, 0, (long)w.n_dirs};
+    return launch_weights_pass<true>(w, src, U, T, d_weights, s, prof);
+}
+
+int sample_ids(const vet_plan* pl, const double* d_mu, const double* d_mv, long n, int32_t* d_out, hipStream_t s) {
+    const vet::SampleSrc src{d_mu, d_mv, nullptr, pl->W, pl->H, (long)pl->n_dirs};
+    hipLaunchKernelGGL(k_sample_ids, dim3(grid_for(n, 256, pl->ctx->n_cu)), dim3(256), 0, s, src, n, d_out);
+    HIP_TRY(hipGetLastError());
+    return VET_OK;
+}
 
 int spatial_set_attrs(vet_ctx* c) {
 #define ATTR_TRY(fn, bytes) HIP_TRY(hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
@@ -602,15 +681,14 @@ int vet_spatial_entropy_ids(vet_plan* pl, const int32_t* d_ids, int U, int T, do
 // Batch of videos in ONE launch (weighted table formulation): short videos are launch-bound one at
 // a time (config 2: 43 us of kernel per call), so their frame blocks share a grid.  Falls back to
 // one call per video when the table formulation does not apply.
-// the descriptors of a batch -> device (pool slot 7); the host copy stays alive in the context
-static int upload_descriptors(vet_ctx* c, const std::vector<vet::VideoDesc>& desc, hipStream_t s, void** d_desc) {
+// the descriptors of a batch -> device, through a slot of the context's blob ring (vh::BatchBlob: neither copy is reused
+// while an earlier batch is pending; the blob's destructor marks the slot behind the launches of this call)
+static int upload_descriptors(vet_ctx* c, const std::vector<vet::VideoDesc>& desc, hipStream_t s, BatchBlob& blob) {
     const size_t bytes = desc.size() * sizeof(vet::VideoDesc);
-    int rc = pooled(c, 7, bytes, d_desc);
+    int rc = blob.acquire(c, bytes);
     if (rc) return rc;
-    c->batch_host.resize(bytes);
-    memcpy(c->batch_host.data(), desc.data(), bytes);
-    HIP_TRY(hipMemcpyAsync(*d_desc, c->batch_host.data(), bytes, hipMemcpyHostToDevice, s));
-    return VET_OK;
+    memcpy(blob.host(), desc.data(), bytes);
+    return blob.upload(s);
 }
 
 // Unweighted (nearest-tile) batch: every video's frame blocks in ONE k_spatial_u_lds launch per lattice; with several
@@ -677,17 +755,17 @@ static int batch_unweighted(vet_plan* pl, int n_videos, const vet_video* videos,
     // descriptors, frame offsets and output pointers go to the device as ONE blob whose host copy the context keeps
     // alive (no synchronisation here: the call only enqueues work, include/vet.h)
     const size_t desc_b = desc.size() * sizeof(vet::VideoDesc), f0_b = frame0.size() * 8, outs_b = outs.size() * 8;
-    void* d_desc = nullptr;
-    int rc = pooled(c, 7, desc_b + f0_b + outs_b, &d_desc);
+    BatchBlob blob;
+    int rc = blob.acquire(c, desc_b + f0_b + outs_b);
     if (rc) return rc;
-    c->batch_host.resize(desc_b + f0_b + outs_b);
-    memcpy(c->batch_host.data(), desc.data(), desc_b);
-    memcpy(c->batch_host.data() + desc_b, frame0.data(), f0_b);
-    memcpy(c->batch_host.data() + desc_b + f0_b, outs.data(), outs_b);
-    char* base = (char*)d_desc;
+    memcpy(blob.host(), desc.data(), desc_b);
+    memcpy((char*)blob.host() + desc_b, frame0.data(), f0_b);
+    memcpy((char*)blob.host() + desc_b + f0_b, outs.data(), outs_b);
+    char* base = (char*)blob.dev();
     long* d_frame0 = (long*)(base + desc_b);
     double** d_outs = (double**)(base + desc_b + f0_b);
-    HIP_TRY(hipMemcpyAsync(base, c->batch_host.data(), c->batch_host.size(), hipMemcpyHostToDevice, s));
+    rc = blob.upload(s);
+    if (rc) return rc;
     for (int k = 0; k < K; ++k) {
         const Lattice& L = pl->lat[k];
         vet::SpatialParams q{};
@@ -772,9 +850,10 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
                 lds_max = lds > lds_max ? lds : lds_max;
             }
             if (fits) {
-                void* d_desc = nullptr;
-                rc = upload_descriptors(c, desc, s, &d_desc);
+                BatchBlob blob;
+                rc = upload_descriptors(c, desc, s, blob);
                 if (rc) return rc;
+                void* d_desc = blob.dev();
                 const vet::SampleSrc src{nullptr, nullptr, nullptr, pl->W, pl->H, (long)pl->n_dirs};
                 bool launched = false;
                 rc = launch_lut_fused<false>(pl, src, 0, 0, (const vet::VideoDesc*)d_desc, n_videos, block, lds_max, max_users,
@@ -815,9 +894,10 @@ int vet_spatial_entropy_batch(vet_plan* pl, int n_videos, const vet_video* video
             lds_max = lds > lds_max ? lds : lds_max;
         }
         if (table) {
-            void* d_desc = nullptr;
-            int rc = upload_descriptors(c, desc, s, &d_desc);
+            BatchBlob blob;
+            int rc = upload_descriptors(c, desc, s, blob);
             if (rc) return rc;
+            void* d_desc = blob.dev();
             int idx[vet::MAX_LATTICES];
             for (int k = 0; k < K; ++k) idx[k] = k;
             const vet::SampleSrc src{nullptr, nullptr, nullptr, pl->W, pl->H, (long)pl->n_dirs};

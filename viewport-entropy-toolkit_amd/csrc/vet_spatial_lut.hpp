@@ -236,7 +236,8 @@ struct LutParams {
 // L = sum v log2 v together, then H = log2 S - L / S: one log2 per tile, one divide per lattice.  Against the
 // term-by-term form -sum (v/S) log2 (v/S) the cancellation costs ~60 ulp ABSOLUTE (2e-14); integer formulations only
 // run on plans whose every frame has an entropy above ~1e-3 (k_row_stats: the bound 36.5 q k / (2 S H) <= 1e-7 needs
-// it), i.e. <= 2e-11 relative.  Canonical order: every lane sums its tiles lane, lane + 64, ... in order, then one fixed
+// it: a frame's entropy is at least the smallest of its rows', entropy being concave), i.e. <= 2e-11 relative; a frame
+// below 1e-6 is evaluated term by term all the same.  Canonical order: every lane sums its tiles lane, lane + 64, ... in order, then one fixed
 // DPP tree -> the same bits whatever the kernel, the frames per workgroup or the launch geometry.
 //   val(t): the histogram value of tile t of this lattice;  wrow: this frame's row of the weights output or null.
 // ------------------------------------------------------------------------------------------
@@ -256,7 +257,19 @@ __device__ __forceinline__ double lattice_entropy_int(int n, V val, double hmax,
     hi = wave_total(hi); lo = wave_total(lo);
     const double S = (double)(hi + (lo >> 32)) * 4294967296.0 + (double)(lo & 0xFFFFFFFFull);
     if (!(S > 0.0)) return 0.0;                 // no tile in any user's FoV: the reference sums over an empty dict
-    return fmax(log2(S) - L / S, 0.0) / hmax;
+    double H = log2(S) - L / S;
+    // The one-pass form loses ~2e-14 ABSOLUTE to cancellation.  The plans that run integer formulations keep every frame
+    // above ~1e-3 (header); should a frame come out lower all the same (one key: exactly 0 in the reference), it is
+    // evaluated again term by term, -sum (v/S) log2 (v/S), which has no cancellation (wave-uniform branch, same order)
+    if (H < 1e-6) {
+        double h = 0.0;
+        for (int t = lane; t < n; t += WAVE) {
+            const unsigned long long v = val(t);
+            if (v != 0ull) { const double q = (double)v / S; h -= q * log2(q); }
+        }
+        H = wave_total(h);
+    }
+    return fmax(H, 0.0) / hmax;
 }
 
 // frames fl = wave, wave + NW, ... of the workgroup: K lattices laid end to end in a frame's histogram row

@@ -86,7 +86,7 @@ __device__ __forceinline__ void keyed_frame_entropy(const double* hist, const in
                 e = __builtin_nan("");
                 if (status) atomicAdd(&status[1], 1);
             }
-            ent_k[f] = e;
+            if (ent_k) ent_k[f] = e;                      // null: weights-only pass
             if (present) present[f] = np;
         }
     }

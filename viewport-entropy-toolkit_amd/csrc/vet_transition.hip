@@ -254,17 +254,17 @@ int vet_transition_entropy_batch(vet_plan* pl, int n_videos, const vet_video* vi
     // descriptors, row offsets and output pointers go to the device as ONE blob whose host copy the context keeps alive
     // (no synchronisation here: the call only enqueues work, include/vet.h)
     const size_t tv_b = tv.size() * sizeof(vet::TransVideo), r0_b = row0.size() * 8, outs_b = outs.size() * 8;
-    void* d_buf = nullptr;
-    int rc = pooled(c, 7, tv_b + r0_b + outs_b, &d_buf);
+    BatchBlob blob;
+    int rc = blob.acquire(c, tv_b + r0_b + outs_b);
     if (rc) return rc;
-    c->batch_host.resize(tv_b + r0_b + outs_b);
-    memcpy(c->batch_host.data(), tv.data(), tv_b);
-    memcpy(c->batch_host.data() + tv_b, row0.data(), r0_b);
-    memcpy(c->batch_host.data() + tv_b + r0_b, outs.data(), outs_b);
-    char* base = (char*)d_buf;
+    memcpy(blob.host(), tv.data(), tv_b);
+    memcpy((char*)blob.host() + tv_b, row0.data(), r0_b);
+    memcpy((char*)blob.host() + tv_b + r0_b, outs.data(), outs_b);
+    char* base = (char*)blob.dev();
     long* d_row0 = (long*)(base + tv_b);
     double** d_outs = (double**)(base + tv_b + r0_b);
-    HIP_TRY(hipMemcpyAsync(base, c->batch_host.data(), c->batch_host.size(), hipMemcpyHostToDevice, s));
+    rc = blob.upload(s);
+    if (rc) return rc;
     const bool exact = min_users == max_users && (long)upt * threads == max_users;
     for (int k = 0; k < K; ++k) {
         const Lattice& L = pl->lat[k];

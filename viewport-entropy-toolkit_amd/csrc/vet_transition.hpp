@@ -302,6 +302,11 @@ __global__ __launch_bounds__(TRANS_BIG_THREADS) void k_transition_big(const Tran
             }
         }
         __syncthreads();
+        // user count per source tile (m_cnt is final here).  Written for EVERY tile in a loop of its own: the passes below
+        // only visit tiles with pass_of[t] < n_pass, and empty tiles behind the last populated one get pass_of = n_pass
+        // when the row's bucket bound is an exact multiple of cap.
+        if (p.srccount)
+            for (int t = tid; t < p.n; t += BD) p.srccount[r * (long)p.n + t] = (int)m_cnt[t];
         // ---- ranges of source tiles: tile t goes to pass floor(bound of the tiles before it / cap), bound = min(m, n)
         if (wv == 0) {
             unsigned carry = 0u;
@@ -363,7 +368,6 @@ __global__ __launch_bounds__(TRANS_BIG_THREADS) void k_transition_big(const Tran
             for (int t = tid; t < p.n; t += BD) {
                 if ((int)pass_of[t] != q) continue;
                 const unsigned m = m_cnt[t];
-                if (p.srccount) p.srccount[r * (long)p.n + t] = (int)m;
                 if (!m) continue;
                 const unsigned K = 1u + k_cnt[t];
                 const unsigned w = m <= 1u ? 1u : hcnt[last_fu[t] & 0x1FFFu];

@@ -22,7 +22,7 @@ LIB_PATH = Path(os.environ.get("VET_HIP_LIBRARY", _PKG_DIR.parent / "lib" / "lib
 
 VET_OK, VET_ERR_INVALID, VET_ERR_DEVICE, VET_ERR_RANGE, VET_ERR_EMPTY, VET_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 KERNEL_IDS = {"k_grid_dirs": 0, "k_nearest_lut": 1, "k_spatial": 2, "k_transition": 3, "k_finalize": 4,
-              "k_wtab": 5}
+              "k_wtab": 5, "k_weights": 6}
 
 
 class NativeUnavailable(RuntimeError):
@@ -87,6 +87,7 @@ SIGNATURES = {
     "vet_plan_destroy": (_I, [_P]),
     "vet_plan_n_dirs": (_I64, [_P]),
     "vet_plan_set_table_policy": (_I, [_P, _I]),
+    "vet_plan_set_raw_weights": (_I, [_P, _I]),
     "vet_plan_table_stride": (_I, [_P, _I]),
     "vet_plan_table_rows": (_I64, [_P]),
     "vet_plan_last_formulation": (_I, [_P, _I]),
@@ -380,6 +381,11 @@ class Plan:
     def set_table_policy(self, policy: int):
         """0 auto, 1 always use the direction weight table, -1 never (brute-force sweep)."""
         _check(self.lib, self.lib.vet_plan_set_table_policy(self.handle, int(policy)))
+
+    def set_raw_weights(self, on: bool = True):
+        """Diagnostic: ``weights`` = the formulation's own histogram (table / sweep resolution) instead of the reference's
+        values from the weights-only pass of the precise sweep (include/vet.h: vet_plan_set_raw_weights)."""
+        _check(self.lib, self.lib.vet_plan_set_raw_weights(self.handle, 1 if on else 0))
 
     def table_stride(self, lattice: int = 0) -> int:
         return int(self.lib.vet_plan_table_stride(self.handle, lattice))

@@ -35,7 +35,7 @@ class TransitionEntropyAnalyzer(_EntropyAnalyzerBase):
         r = int(np.argmin(common))                 # first row without a common user
         if not present[r].any() or not present[r + 1].any():
             return ValidationError("Empty vector dictionary")
-        return ZeroDivisionError("float division by zero")
+        return ZeroDivisionError("division by zero")          # `1 / total_weight` with the int 0 (:326)
 
     def compute_entropy(self) -> pd.DataFrame:
         kind, times, a, b, names = self._samples()

@@ -131,7 +131,7 @@ def compute_transition_entropy(prior_vector_dict: dict, current_vector_dict: dic
         raise ValidationError("No tile centers provided")
     users = [k for k in current_vector_dict if k in prior_vector_dict]
     if not users:
-        raise ZeroDivisionError("float division by zero")
+        raise ZeroDivisionError("division by zero")          # the reference's `1 / total_weight` with the int 0 (:326)
     vecs = [prior_vector_dict[k] for k in users] + [current_vector_dict[k] for k in users]
     plan = _plan_for(vecs, tile_centers, EntropyConfig())
     try:
