@@ -57,6 +57,17 @@ struct WeightsCore {
     int n0 = 0;
     int64_t n_dirs = 0;
     double cos_cull = 0.0, max_ang = 0.0, power = 2.0;
+    // Exact weight rows of lattice 0 (k_wexact, built on the first request for weights): one ELL row per canonical
+    // direction holding the tile and the exact FP64 weight of every tile with distance < fov/2 — zero-valued keys included.
+    // The weights pass then gathers rows (k_weights_gather) instead of sweeping every tile with acos / pow per sample.
+    struct Exact {
+        int state = 0;                 // 0 not built, 1 ready, -1 not usable (too large for the device): precise sweep instead
+        int stride = 0, n_rows = 0;
+        std::shared_ptr<void> alias;   // [n_dirs] u32  direction -> row | mirrored << 31
+        std::shared_ptr<void> idx;     // [n_rows][stride] u16 tiles
+        std::shared_ptr<void> w;       // [n_rows][stride] f64 weights
+        std::shared_ptr<void> len;     // [n_rows] u32 entries in use
+    } ex;
 };
 
 // One slot of the batch-descriptor ring (vet_ctx::stage)
@@ -92,6 +103,7 @@ struct Tuning {
     int fused_single = 0;       // VET_FUSED: fused table also for one-lattice plans
     int lut_occ8 = -1;          // VET_LUT_OCC8 (fused table kernel: -1 by shape)
     int fused_narrow = 1;       // VET_FUSED_NARROW: 8-lane rows for fused rows of 65..96 entries
+    int narrow_deal = 1;        // VET_NARROW_DEAL: class-dealt blocks for those 8-lane rows (0: plain order, round 4)
     void from_environment();
 };
 
@@ -189,7 +201,7 @@ struct vet_plan {
         uint32_t* d_w = nullptr;   // [R+1][stride]
         uint16_t* d_i = nullptr;   // [R+1][stride]
     } fused;
-    vh::WeightsCore wcore;         // owner of d_dir_unit and lat[0].d_tiles (shared with device-resident results)
+    std::shared_ptr<vh::WeightsCore> wcore;   // owner of d_dir_unit and lat[0].d_tiles (shared with device-resident results)
     bool stats_all = false;        // k_row_stats has run for every weighted lattice
     bool ultra = false;            // some lattice has ultra-tiny in-FoV weights: FP64 formulations only (plan-wide)
 };
@@ -255,6 +267,8 @@ bool any_binned(const vet_plan* pl);
 // vet_spatial.hip: tile_weights of lattice 0 for frames [0, T) of a sample array given as direction ids, by the precise
 // sweep in weights-only mode (users in column order); prof = context to attribute the launch to, or null
 int weights_pass_ids(const WeightsCore& w, const int32_t* d_ids, int U, int T, double* d_weights, hipStream_t s, vet_ctx* prof);
+// vet_plan.hip: the exact weight rows of lattice 0 (first use; synchronises once).  Leaves ex.state = -1 when they do not fit.
+int ensure_exact_weights(vet_plan* pl, hipStream_t s);
 // (mu, mv) -> direction ids [n] (-1 absent or out of range) on the plan's pixel grid
 int sample_ids(const vet_plan* pl, const double* d_mu, const double* d_mv, long n, int32_t* d_out, hipStream_t s);
 

@@ -21,7 +21,7 @@ struct vet_result {
     // the reference's values (exact weights, column order) whatever formulation produced the entropy, and 120 MB less
     // to write on the hot path of BASELINE config 3.
     bool lazy_weights = false;
-    WeightsCore core;
+    std::shared_ptr<WeightsCore> core;
     int32_t* d_ids = nullptr;
     int U = 0;
     void* d_tmp = nullptr;               // grow-only staging of the fetched weight rows
@@ -66,6 +66,10 @@ static int run_host(vet_plan* pl, bool transition, const double* h_mu, const dou
         res->row_bytes[1] = transition ? (size_t)n0 * 4 : (size_t)n0 * 8;
         res->lazy_weights = !transition && pl->weighted && !pl->lat[0].binned && !pl->raw_weights;
         bool ok = hipMalloc(&res->d[0], a_bytes ? a_bytes : 8) == hipSuccess;
+        if (res->lazy_weights) {
+            rc = ensure_exact_weights(pl, s);      // the rows a fetched block gathers (precise sweep if they do not fit)
+            if (rc) { delete res; return rc; }
+        }
         if (ok && res->lazy_weights) {
             res->core = pl->wcore; res->U = U;
             ok = hipMalloc((void**)&res->d_ids, S * 4 ? S * 4 : 8) == hipSuccess;
@@ -152,7 +156,7 @@ int vet_result_fetch(vet_result* r, int which, int64_t row0, int64_t n_rows, voi
             HIP_TRY(hipMalloc(&r->d_tmp, bytes));
             r->tmp_cap = bytes;
         }
-        int rc = weights_pass_ids(r->core, r->d_ids + (size_t)row0 * r->U, r->U, (int)n_rows, (double*)r->d_tmp, nullptr, nullptr);
+        int rc = weights_pass_ids(*r->core, r->d_ids + (size_t)row0 * r->U, r->U, (int)n_rows, (double*)r->d_tmp, nullptr, nullptr);
         if (rc) return rc;
         HIP_TRY(hipMemcpy(h_dst, r->d_tmp, bytes, hipMemcpyDeviceToHost));
         return VET_OK;

@@ -10,12 +10,18 @@
 //                       vet_weight_table.hpp   k_row_stats      exact rows -> error bounds of the integer formulations
 //                                              k_wtab           direction -> ELL row of (tile, FoV weight), ocml acos / pow
 //                                              k_fuse_shifts, k_dirrec   fused-row shifts, per-direction records
+//                                              k_wexact         direction -> ELL row of (tile, exact FP64 weight) of lattice 0:
+//                                                               the rows the weights pass gathers
 //                       vet_geometry.hpp       k_fb_boundaries  tile boundary edges of a Fibonacci tiling
 //   vet_spatial.hip     vet_spatial_lut.hpp    k_spatial_lut    table formulation: per frame, samples -> direction ids ->
 //                                                               gather of the users' rows into 64-bit integer (or FP64) LDS
 //                                                               histograms (all lattices in one launch) -> Shannon entropy
 //                       vet_spatial_sweep.hpp  k_spatial_w      sweep formulations (few samples per plan): lane = tile, FP64
 //                                                               cone test per (user, tile), full-wave weight evaluation
+//                       vet_weights_pass.hpp   k_weights_gather the tile_weights output (values at the reference's precision):
+//                                                               per frame, the users' exact weight rows summed in column
+//                                                               order (off the hot path; k_spatial_w<PRECISE> in weights-only
+//                                                               mode where the exact rows do not fit the device)
 //                       vet_spatial_u.hpp      k_spatial_u_lds  nearest-tile (unweighted) and naive lat/lon-grid mode:
 //                                                               persistent stream with the nearest LUT in LDS (HBM-bound)
 //                                              k_spatial_u      generic fallback (LUT gathered from global memory)

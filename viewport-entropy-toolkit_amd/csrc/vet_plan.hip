@@ -242,6 +242,64 @@ int ensure_wtab(vet_plan* pl, int k, hipStream_t s) {
     return VET_OK;
 }
 
+// Exact FP64 weight rows of lattice 0 for the weights pass (vet_host.hpp: WeightsCore::Exact).  Rows = the plan's
+// canonical directions (ensure_alias: a direction and its mirror image share a row; the dot products are identical bit
+// for bit, so are the weights).  10 bytes per entry; capped at a quarter of the free device memory and 8 GB.
+int ensure_exact_weights(vet_plan* pl, hipStream_t s) {
+    WeightsCore::Exact& X = pl->wcore->ex;
+    if (X.state != 0) return VET_OK;
+    vet_ctx* c = pl->ctx;
+    const Lattice& L = pl->lat[0];
+    if (!pl->weighted || L.binned || !L.d_tiles) { X.state = -1; return VET_OK; }
+    int rc = ensure_alias(pl);
+    if (rc) return rc;
+    const long R = pl->n_rows;
+    if (R <= 0) { X.state = -1; return VET_OK; }
+    DevBuf d_max;
+    HIP_TRY(d_max.alloc(sizeof(int)));
+    HIP_TRY(hipMemsetAsync(d_max.p, 0, sizeof(int), s));
+    vet::WtabParams p{};
+    p.dir_unit = pl->d_dir_unit; p.D = R;
+    p.canon = pl->d_canon; p.shift_by_dir = 1; p.nl = 0;
+    p.tiles = L.d_tiles; p.n = L.n;
+    p.cos_cull = pl->cos_cull;
+    p.wc.max_ang = pl->max_ang; p.wc.inv_max = 1.0 / pl->max_ang; p.wc.power = pl->power; p.wc.shift = 0;
+    p.maxcount = (int*)d_max.p; p.gs_log2 = -1;
+    const int blocks = grid_for(R * vet::WAVE, 256, c->n_cu * 2);
+    hipLaunchKernelGGL(vet::k_wtab<false>, dim3(blocks), dim3(256), 0, s, p);       // longest row (conservative cone test)
+    int longest = 0;
+    HIP_TRY(hipMemcpyAsync(&longest, d_max.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const int stride = ((longest > 0 ? longest : 1) + 63) / 64 * 64;
+    const size_t D = (size_t)pl->n_dirs, entries = (size_t)R * stride, bytes = entries * 10 + (size_t)R * 4 + D * 4;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    if (bytes > ((size_t)8 << 30) || bytes > free_b / 4 || stride > 65535) { X.state = -1; return VET_OK; }
+    auto dev_free = [](void* q) { if (q) (void)hipFree(q); };
+    auto dev_alloc = [&](size_t b) {
+        void* q = nullptr;
+        if (hipMalloc(&q, b ? b : 8) != hipSuccess) { (void)hipGetLastError(); q = nullptr; }
+        return std::shared_ptr<void>(q, dev_free);
+    };
+    auto alias = dev_alloc(D * 4), idx = dev_alloc(entries * 2), w = dev_alloc(entries * 8), len = dev_alloc((size_t)R * 4);
+    if (!alias || !idx || !w || !len) return VET_OK;      // out of memory today: the precise sweep serves, a later call retries
+    HIP_TRY(hipMemcpyAsync(alias.get(), pl->d_alias, D * 4, hipMemcpyDeviceToDevice, s));
+    vet::WexactParams q{};
+    q.dir_unit = pl->d_dir_unit; q.canon = pl->d_canon; q.R = R; q.tiles = L.d_tiles; q.n = L.n;
+    q.cos_cull = pl->cos_cull; q.wc = p.wc; q.stride = stride;
+    q.idx = (uint16_t*)idx.get(); q.w = (double*)w.get(); q.len = (uint32_t*)len.get();
+    {
+        ProfScope ps(c, s, KID_WTAB);
+        hipLaunchKernelGGL(vet::k_wexact, dim3(blocks), dim3(256), 0, s, q);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));          // complete before this returns: a later fetch may run on another stream
+    X.alias = alias; X.idx = idx; X.w = w; X.len = len;
+    X.stride = stride; X.n_rows = (int)R;
+    X.state = 1;
+    return VET_OK;
+}
+
 bool any_binned(const vet_plan* pl) {
     for (const auto& L : pl->lat) if (L.binned) return true;
     return false;
@@ -356,7 +414,9 @@ int ensure_fused(vet_plan* pl, hipStream_t s) {
     // empty (config 4: 88-94 entries: 128 -> 96 slots per row walk)
     if (longest > 64 && longest <= 96 && c->tune.fused_narrow) F.gs_log2 = 3;
     if (c->tune.gs_log2) F.gs_log2 = c->tune.gs_log2;
-    F.interleaved = F.gs_log2 == 4 && 4 * longest >= 3 * 64 && c->tune.tab_interleave != 0;
+    // class-dealt blocks (k_wtab): 16-lane rows with a block of 64 at least 3/4 full, 8-lane rows with one of 32
+    F.interleaved = ((F.gs_log2 == 4 && 4 * longest >= 3 * 64) || (F.gs_log2 == 3 && 4 * longest >= 3 * 32 && c->tune.narrow_deal)) &&
+                    c->tune.tab_interleave != 0;
     p.stride = stride; p.w = F.d_w; p.idx = F.d_i; p.meta = F.d_meta; p.maxcount = nullptr;
     p.gs_log2 = F.interleaved ? F.gs_log2 : -1;
     {
@@ -502,7 +562,8 @@ int vet_plan_create(vet_ctx* c, const vet_plan_desc* d, vet_plan** out) {
 #undef PLAN_TRY
     {   // the weights-only pass (vet_host.hpp: WeightsCore) shares the direction table and lattice 0's tiles
         auto dev_free = [](void* q) { if (q) (void)hipFree(q); };
-        vh::WeightsCore& w = pl->wcore;
+        pl->wcore = std::make_shared<vh::WeightsCore>();
+        vh::WeightsCore& w = *pl->wcore;
         w.device = c->device; w.lds_max = c->lds_max; w.n_cu = c->n_cu;
         w.dir_unit = std::shared_ptr<void>((void*)pl->d_dir_unit, dev_free);
         if (pl->lat[0].d_tiles) w.tiles0 = std::shared_ptr<void>((void*)pl->lat[0].d_tiles, dev_free);
@@ -519,9 +580,9 @@ int vet_plan_destroy(vet_plan* pl) {
     (void)hipStreamSynchronize(pl->ctx->stream);
     if (pl->d_dir_raw) (void)hipFree(pl->d_dir_raw);
     // d_dir_unit and lat[0].d_tiles belong to pl->wcore once the plan is complete (shared with device-resident results)
-    if (pl->d_dir_unit && !pl->wcore.dir_unit) (void)hipFree(pl->d_dir_unit);
+    if (pl->d_dir_unit && !(pl->wcore && pl->wcore->dir_unit)) (void)hipFree(pl->d_dir_unit);
     for (auto& L : pl->lat) {
-        if (L.d_tiles && !(&L == &pl->lat[0] && pl->wcore.tiles0)) (void)hipFree(L.d_tiles);
+        if (L.d_tiles && !(&L == &pl->lat[0] && pl->wcore && pl->wcore->tiles0)) (void)hipFree(L.d_tiles);
         if (L.d_nearest) (void)hipFree(L.d_nearest);
         if (L.d_tab_w) (void)hipFree(L.d_tab_w);
         if (L.d_tab_i) (void)hipFree(L.d_tab_i);

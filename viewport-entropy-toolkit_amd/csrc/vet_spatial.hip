@@ -4,6 +4,7 @@
 #include "vet_host.hpp"
 #include "vet_finalize.hpp"
 #include "vet_spatial_sweep.hpp"
+#include "vet_weights_pass.hpp"
 #include "vet_spatial_lut.hpp"
 #include "vet_spatial_u.hpp"
 
@@ -88,8 +89,9 @@ const void* lut_kernel_fused(bool il, bool occ8, bool dedup, bool narrow = false
     // narrow: rows of 8-lane groups (32-entry blocks; fused rows of 65..96 entries fill three of them instead of two half-empty
     // 64-entry ones): two rows in flight per lane group keep a wave at 16 rows per step, as four do with 16-lane groups
     if (narrow) {
-#define VET_PICKN(O, D) if (occ8 == O && dedup == D) return (const void*)vet::k_spatial_lut<FROM_IDS, 2, false, O, D, false, true>
-        VET_PICKN(false, false); VET_PICKN(true, false); VET_PICKN(false, true); VET_PICKN(true, true);
+#define VET_PICKN(I, O, D) if (il == I && occ8 == O && dedup == D) return (const void*)vet::k_spatial_lut<FROM_IDS, 2, I, O, D, false, true>
+        VET_PICKN(false, false, false); VET_PICKN(false, true, false); VET_PICKN(false, false, true); VET_PICKN(false, true, true);
+        VET_PICKN(true, false, false); VET_PICKN(true, true, false); VET_PICKN(true, false, true); VET_PICKN(true, true, true);
 #undef VET_PICKN
     }
 #define VET_PICK(I, O, D) if (il == I && occ8 == O && dedup == D) return (const void*)vet::k_spatial_lut<FROM_IDS, VET_FUSED_UN, I, O, D, false, true>
@@ -291,8 +293,8 @@ int launch_lut_fused(vet_plan* pl, const vet::SampleSrc& src, int U, int T, cons
     const bool occ8 = c->tune.lut_occ8 >= 0 ? c->tune.lut_occ8 != 0 : (F.gs_log2 == 3 && !d_videos && dedup);
 #if VET_STAGE_CYCLES
     DevBuf dbg;                               // development builds: cycles per stage (thread 0 of every workgroup), synchronous
-    HIP_TRY(dbg.alloc(32));
-    HIP_TRY(hipMemsetAsync(dbg.p, 0, 32, s));
+    HIP_TRY(dbg.alloc(64));
+    HIP_TRY(hipMemsetAsync(dbg.p, 0, 64, s));
     q.dbg = (unsigned long long*)dbg.p;
 #endif
     {
@@ -303,11 +305,13 @@ int launch_lut_fused(vet_plan* pl, const vet::SampleSrc& src, int U, int T, cons
     }
 #if VET_STAGE_CYCLES
     {
-        unsigned long long t[4] = {};
-        HIP_TRY(hipMemcpyAsync(t, dbg.p, 32, hipMemcpyDeviceToHost, s));
+        unsigned long long t[8] = {};
+        HIP_TRY(hipMemcpyAsync(t, dbg.p, 64, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        fprintf(stderr, "[k_spatial_lut fused] blocks %d FPW %d lds %zu | cycles per workgroup (thread 0): samples->set %.0f  lists %.0f  walk %.0f  entropy %.0f\n",
-                blocks, q.FPW, lds, (double)t[0] / blocks, (double)t[1] / blocks, (double)t[2] / blocks, (double)t[3] / blocks);
+        fprintf(stderr, "[k_spatial_lut fused] blocks %d FPW %d lds %zu | cycles per workgroup (thread 0): samples->set %.0f  lists %.0f  walk %.0f  entropy %.0f"
+                        " | samples->set = init %.0f + sample loads %.0f + record gathers %.0f + inserts %.0f (+ barrier)\n",
+                blocks, q.FPW, lds, (double)t[0] / blocks, (double)t[1] / blocks, (double)t[2] / blocks, (double)t[3] / blocks,
+                (double)t[4] / blocks, (double)t[5] / blocks, (double)t[6] / blocks, (double)t[7] / blocks);
     }
 #endif
     *launched = true;
@@ -395,6 +399,32 @@ template <bool FROM_IDS>
 int launch_weights_pass(const WeightsCore& w, const vet::SampleSrc& src, int U, int T, double* d_weights, hipStream_t s,
                         vet_ctx* prof) {
     if (T <= 0) return VET_OK;
+    if (w.ex.state == 1) {
+        // the exact weight rows exist (ensure_exact_weights): gather them, one workgroup per frame
+        int nw = 4;
+        while (nw > 1 && (size_t)nw * w.n0 * 8 > w.lds_max) nw /= 2;
+        if ((size_t)nw * w.n0 * 8 <= w.lds_max) {
+            vet::WeightsGatherParams q{};
+            q.src = src; q.U = U; q.T = T;
+            q.alias = (const uint32_t*)w.ex.alias.get(); q.idx = (const uint16_t*)w.ex.idx.get();
+            q.w = (const double*)w.ex.w.get(); q.len = (const uint32_t*)w.ex.len.get();
+            q.stride = w.ex.stride; q.n = w.n0; q.out = d_weights;
+            const int chunks = w.ex.stride / vet::WAVE;
+            const void* fn = chunks <= 1 ? (const void*)vet::k_weights_gather<FROM_IDS, 1>
+                           : chunks <= 2 ? (const void*)vet::k_weights_gather<FROM_IDS, 2>
+                           : chunks <= 4 ? (const void*)vet::k_weights_gather<FROM_IDS, 4> : (const void*)vet::k_weights_gather<FROM_IDS, 0>;
+            void* args[] = {(void*)&q};
+            const size_t lds = (size_t)nw * w.n0 * 8;
+            if (prof) {
+                ProfScope ps(prof, s, KID_WEIGHTS);
+                HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)T), dim3(nw * vet::WAVE), args, lds, s));
+            } else {
+                HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)T), dim3(nw * vet::WAVE), args, lds, s));
+            }
+            HIP_TRY(hipGetLastError());
+            return VET_OK;
+        }
+    }
     Geometry g;
     int rc = sweep_geometry(w.lds_max, w.n0, U, &g);
     if (rc) return rc;
@@ -438,7 +468,9 @@ int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double
     int rc = launch_spatial_main<FROM_IDS>(pl, src, U, T, d_entropy, d_assign, exact ? nullptr : d_weights,
                                            exact ? d_weights : nullptr, &wrote, d_present, d_status, s);
     if (rc || !exact || wrote) return rc;
-    return launch_weights_pass<FROM_IDS>(pl->wcore, src, U, T, d_weights, s, pl->ctx);
+    rc = ensure_exact_weights(pl, s);          // first request for weights: the exact rows of lattice 0 (or not, if too large)
+    if (rc) return rc;
+    return launch_weights_pass<FROM_IDS>(*pl->wcore, src, U, T, d_weights, s, pl->ctx);
 }
 
 // d_weights: written by whatever formulation runs (unweighted / binned plans: integer counts, exact);
@@ -628,8 +660,8 @@ int spatial_set_attrs(vet_ctx* c) {
     for (int v = 0; v < 8; ++v) {
         ATTR_TRY(lut_kernel_fused<false>(v & 1, v & 2, v & 4), c->lds_max);
         ATTR_TRY(lut_kernel_fused<true>(v & 1, v & 2, v & 4), c->lds_max);
-        ATTR_TRY(lut_kernel_fused<false>(false, v & 2, v & 4, true), c->lds_max);
-        ATTR_TRY(lut_kernel_fused<true>(false, v & 2, v & 4, true), c->lds_max);
+        ATTR_TRY(lut_kernel_fused<false>(v & 1, v & 2, v & 4, true), c->lds_max);
+        ATTR_TRY(lut_kernel_fused<true>(v & 1, v & 2, v & 4, true), c->lds_max);
         ATTR_TRY(lut_kernel<false>(v & 1, v & 2, v & 4), c->lds_max);
         ATTR_TRY(lut_kernel<true>(v & 1, v & 2, v & 4), c->lds_max);
         if (!(v & 2)) {
@@ -637,6 +669,10 @@ int spatial_set_attrs(vet_ctx* c) {
             ATTR_TRY(lut_kernel<true>(v & 1, false, v & 4, true), c->lds_max);
         }
     }
+    ATTR_TRY((vet::k_weights_gather<false, 0>), c->lds_max); ATTR_TRY((vet::k_weights_gather<true, 0>), c->lds_max);
+    ATTR_TRY((vet::k_weights_gather<false, 1>), c->lds_max); ATTR_TRY((vet::k_weights_gather<true, 1>), c->lds_max);
+    ATTR_TRY((vet::k_weights_gather<false, 2>), c->lds_max); ATTR_TRY((vet::k_weights_gather<true, 2>), c->lds_max);
+    ATTR_TRY((vet::k_weights_gather<false, 4>), c->lds_max); ATTR_TRY((vet::k_weights_gather<true, 4>), c->lds_max);
     ATTR_TRY((vet::k_spatial_u_lds<false, true, true>), c->lds_max);
     ATTR_TRY((vet::k_spatial_u_lds<false, false, true>), c->lds_max);
     ATTR_TRY((vet::k_spatial_u_lds<false, true>), c->lds_max);

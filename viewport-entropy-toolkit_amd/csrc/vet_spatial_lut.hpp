@@ -7,6 +7,16 @@
 #ifndef VET_STAGE_CYCLES
 #define VET_STAGE_CYCLES 0
 #endif
+// Timing-only experiments (WRONG results; never in the product build, see csrc/Makefile VARIANT): what a table row of fewer
+// cache lines could buy at best.  VET_EXP_SYNTH_IDX: the tile indices are not loaded but synthesised from the lane (a
+// row = its 4-byte weights only: 4 lines instead of 6 at 501 tiles — the per-row bitmap format with a FREE decode);
+// VET_EXP_EXTRA_VALU = k: k more dependent VALU operations per entry (what a real decode would add).
+#ifndef VET_EXP_SYNTH_IDX
+#define VET_EXP_SYNTH_IDX 0
+#endif
+#ifndef VET_EXP_EXTRA_VALU
+#define VET_EXP_EXTRA_VALU 0
+#endif
 
 namespace vet {
 
@@ -69,7 +79,8 @@ __device__ __forceinline__ void lds_add_u64(uint32_t lds_byte_address, unsigned 
 // weights' dynamic range), scaled by 2^E of their row; the histogram is FP64 (ds_add_f64) in true units.
 // marked / bit0: FP tables with marker entries (vet_weight_table.hpp) — bitmap of the frame's tiles (bit0 = the lattice's
 // first bit) that were hit by a marker; null when the launch's tables hold none.
-template <int UN, bool INTERLEAVED, bool DEDUP, bool FPT>
+// GSL_IL: lanes per row (log2) of the class-dealt layout this walk is compiled for (16-lane rows; 8-lane fused rows)
+template <int UN, bool INTERLEAVED, bool DEDUP, bool FPT, int GSL_IL = 4>
 __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t* fmeta, int nu,
                                           unsigned long long* hrow, int n,
                                           const uint32_t* __restrict__ tab_w, const uint16_t* __restrict__ tab_i,
@@ -80,7 +91,7 @@ __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t*
     // unconditional ds_add_u64 of entry * (multiplicity << row shift): padding slots and idle lanes
     // (which walk the all-zero row) add 0 to distinct tiles — no predicates around the adds.
     const int NW = blockDim.x >> 6, lane = lane_id(), wv = wave_id();
-    const int gs_log2 = INTERLEAVED ? 4 : gs_log2_rt;       // class-dealt rows are 16-lane rows (ensure_wtab)
+    const int gs_log2 = INTERLEAVED ? GSL_IL : gs_log2_rt;  // class-dealt rows: the layout's own group size (ensure_wtab / ensure_fused)
     const int GS = 1 << gs_log2, UPW = WAVE >> gs_log2;
     const int sub = lane >> gs_log2, sl = lane & (GS - 1);
     const int step = NW * UPW;
@@ -130,7 +141,25 @@ __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t*
 #pragma unroll
             for (int k = 0; k < UN; ++k) {
                 w[k] = *(const uint4*)(tab_w + r[k]);
+#if VET_EXP_SYNTH_IDX
+                // conflict-free like the class-dealt rows: component c of the 16 lanes of a row = 16 consecutive tiles
+                // (8-lane rows: the two rows of a hardware group take complementary halves of the 16 classes)
+                const unsigned short t0 = (unsigned short)((eb + sl + 8 * (sub & 1) + 64 * k) % (n - 64));
+                t[k] = make_ushort4(t0, (unsigned short)(t0 + 16), (unsigned short)(t0 + 32), (unsigned short)(t0 + 48));
+#else
                 t[k] = *(const ushort4*)(tab_i + r[k]);
+#endif
+#if VET_EXP_EXTRA_VALU
+                {   // dependent integer operations on the loaded words (rotate-xor chains the compiler cannot fold)
+                    uint32_t a = w[k].x, b = w[k].y, c = w[k].z, d = w[k].w;
+#pragma unroll
+                    for (int e = 0; e < VET_EXP_EXTRA_VALU; ++e) {
+                        a = __builtin_amdgcn_alignbit(a, a, 7) ^ b; b = __builtin_amdgcn_alignbit(b, b, 9) ^ c;
+                        c = __builtin_amdgcn_alignbit(c, c, 11) ^ d; d = __builtin_amdgcn_alignbit(d, d, 13) ^ a;
+                    }
+                    w[k] = make_uint4(a, b, c, d);
+                }
+#endif
             }
 #pragma unroll
             for (int k = 0; k < UN; ++k) {
@@ -412,12 +441,21 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
     const long f0 = blk * FPW;
     const int nf = (int)min((long)FPW, (long)T - f0);
 #if VET_STAGE_CYCLES
-    unsigned long long tdbg[4] = {0, 0, 0, 0}, tlast = p.dbg ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long tdbg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = p.dbg ? __builtin_readcyclecounter() : 0ull, tsub = tlast;
     auto stage = [&](int i) {
-        if (p.dbg) { const unsigned long long now = __builtin_readcyclecounter(); tdbg[i] += now - tlast; tlast = now; }
+        if (p.dbg) { const unsigned long long now = __builtin_readcyclecounter(); tdbg[i] += now - tlast; tlast = now; tsub = now; }
+    };
+    // parts of stage 0 (samples -> set): 4 LDS init + barriers, 5 sample loads (waited for), 6 record gathers (waited for),
+    // 7 set inserts + list appends
+    auto sub = [&](int i, bool wait_vm) {
+        if (p.dbg) {
+            if (wait_vm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long now = __builtin_readcyclecounter(); tdbg[4 + i] += now - tsub; tsub = now;
+        }
     };
 #else
     auto stage = [](int) {};
+    auto sub = [](int, bool) {};
 #endif
     if (!overlay)
         for (int i = tid; i < FPW * p.n_sum * PRIV; i += blockDim.x) hist[i] = 0ull;
@@ -433,10 +471,11 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
         if (merge)
             for (int i = tid; i < FPW * HS; i += blockDim.x) hash[i] = EMPTY_KEY;
         __syncthreads();
-        // SPT samples per thread and round: all sample loads first, then the table gathers, then the LDS set
-        // inserts — three waves of independent requests instead of SPT dependent chains
         constexpr int SPT = 4;
         const int total = nf * uc;
+        // SPT samples per thread and round: all sample loads first, then the table gathers, then the LDS set
+        // inserts — three waves of independent requests instead of SPT dependent chains
+        sub(0, false);
         for (int i0 = tid; i0 < total; i0 += SPT * (int)blockDim.x) {
             int id[SPT], fls[SPT];
             long idxs[SPT];
@@ -465,6 +504,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
                         b[k] = __builtin_nontemporal_load(src.mv + idxs[k]);
                     }
                 }
+                sub(1, true);
 #pragma unroll
                 for (int k = 0; k < SPT; ++k) id[k] = grid_dir(a[k], b[k], src.W, src.H, bad);
             }
@@ -490,6 +530,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
                     }
                 }
             }
+            sub(2, true);
             if (assign) {
 #pragma unroll
                 for (int k = 0; k < SPT; ++k)
@@ -545,6 +586,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
                 }
             }
         }
+        sub(3, false);
         __syncthreads();
         stage(0);
         if (DEDUP) {
@@ -658,9 +700,10 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
                     if (j < cnt_chunk[fl]) meta[i] = L.tab_meta[DEDUP ? (rows[i] >> 12) & ROW_MASK : rows[i] & 0x7FFFFFFFu];
                 }
             __syncthreads();
+            constexpr int GSL_IL = (FUSED && UN == 2) ? 3 : 4;      // the narrow fused kernel walks 8-lane rows
             for (int fl = 0; fl < nf; ++fl)
                 if (IL && L.interleaved)
-                    walk_rows<UN, true, DEDUP, FPT>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
+                    walk_rows<UN, true, DEDUP, FPT, GSL_IL>(rows + (size_t)fl * UC, meta + (size_t)fl * UC, cnt_chunk[fl],
                                                hist + ((size_t)fl * PRIV + (FPT ? wv : 0)) * p.n_sum + hoff, L.n, L.tab_w, L.tab_i, L.stride, L.gs_log2,
                                                L.zrow * (uint32_t)L.stride, marked ? marked + (size_t)fl * MW : nullptr, hoff);
                 else
@@ -733,7 +776,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
     if (p.dbg) {
         stage(3);
         if (tid == 0)
-            for (int i = 0; i < 4; ++i) atomicAdd(&p.dbg[i], tdbg[i]);
+            for (int i = 0; i < 8; ++i) atomicAdd(&p.dbg[i], tdbg[i]);
     }
 #endif
     if (p.status) {

@@ -258,13 +258,21 @@ __global__ void k_wtab(const WtabParams p) {
             if (lane == 0) {
                 if (p.meta) p.meta[d] = (uint32_t)count | ((uint32_t)row_shift << 16);
             }
-            // well-filled blocks of 16-lane rows: deal the entries by class (one wave pass per block, lane =
-            // sorted entry; the loads of all lanes have returned before the first store issues)
-            if (p.gs_log2 == 4) {
-                for (int eb = 0; eb < count; eb += WAVE) {
-                    if (!block_interleaved(count, eb, p.gs_log2)) continue;
+            // well-filled blocks of 16- and 8-lane rows: deal the entries by class (one wave pass per block, lane =
+            // sorted entry; the loads of all lanes have returned before the first store issues).
+            // 16-lane rows (blocks of 64): the r-th entry of a class goes to component r mod 4 — one entry per class and
+            // component: a hardware group of 16 lanes is one row and conflict-free.
+            // 8-lane rows (blocks of 32; fused rows of 65..96 entries): a component has 8 places, so the classes are
+            // split into two halves: the r-th entry of a class of half h goes to component (2 r + h) mod 4 — conflict-
+            // free inside the row; the two rows that share a hardware group overlap by chance (the plain order put
+            // one class into all eight lanes of a component: entries ~4 slots apart, four per lane).
+            if (p.gs_log2 == 4 || p.gs_log2 == 3) {
+                const int GSL = p.gs_log2, GS = 1 << GSL, B = 4 * GS;
+                const bool active = lane < B;
+                for (int eb = 0; eb < count; eb += B) {
+                    if (!block_interleaved(count, eb, GSL)) continue;
                     __threadfence_block();
-                    const bool real = eb + lane < count;
+                    const bool real = active && eb + lane < count;
                     uint32_t wv = 0; uint16_t iv = 0;
                     if (real) { wv = p.w[d * p.stride + eb + lane]; iv = p.idx[d * p.stride + eb + lane]; }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -274,13 +282,13 @@ __global__ void k_wtab(const WtabParams p) {
                         const unsigned long long m = __ballot(real && cls == c);
                         if (real && cls == c) r = below(m);
                     }
-                    int comp = r & 3, q = 0, used[4], freeb[5];
-                    for (int k = 0; k < 4; ++k) {                // lane inside the component, 16 places each
+                    int comp = (r * (16 >> GSL) + (cls >> GSL)) & 3, q = 0, used[4], freeb[5];
+                    for (int k = 0; k < 4; ++k) {                // lane inside the component, GS places each
                         const unsigned long long m = __ballot(real && comp == k);
                         if (real && comp == k) q = below(m);
-                        used[k] = min(16, (int)__popcll(m));
+                        used[k] = min(GS, (int)__popcll(m));
                     }
-                    const bool placed = real && q < 16;
+                    const bool placed = real && q < GS;
                     unsigned usedmask[4];                        // classes present in each component
                     for (int k = 0; k < 4; ++k) {
                         usedmask[k] = 0;
@@ -288,9 +296,11 @@ __global__ void k_wtab(const WtabParams p) {
                             if (__ballot(placed && comp == k && cls == c)) usedmask[k] |= 1u << c;
                     }
                     freeb[0] = 0;
-                    for (int k = 0; k < 4; ++k) freeb[k + 1] = freeb[k] + 16 - used[k];
-                    if (!placed) {                               // leftovers take the free places in order
-                        const int j = below(__ballot(!placed));
+                    for (int k = 0; k < 4; ++k) freeb[k + 1] = freeb[k] + GS - used[k];
+                    const bool leftover = active && !placed;     // entries beyond a component's places, and the padding
+                    const unsigned long long lm = __ballot(leftover);
+                    if (leftover) {                              // they take the free places in order
+                        const int j = below(lm);
                         int k = 0;
                         while (k < 3 && j >= freeb[k + 1]) ++k;
                         const int jj = j - freeb[k];
@@ -300,11 +310,13 @@ __global__ void k_wtab(const WtabParams p) {
                             for (; c < 15; ++c) {
                                 if (!((usedmask[k] >> c) & 1u)) { if (seen == jj) break; ++seen; }
                             }
-                            iv = (uint16_t)c;                    // tile c has class c (n > 16 for 16-lane rows)
+                            iv = (uint16_t)c;                    // slot c has class c (more than 16 slots in such rows)
                         }
                     }
-                    p.w[d * p.stride + eb + q * 4 + comp] = wv;
-                    p.idx[d * p.stride + eb + q * 4 + comp] = iv;
+                    if (active) {
+                        p.w[d * p.stride + eb + q * 4 + comp] = wv;
+                        p.idx[d * p.stride + eb + q * 4 + comp] = iv;
+                    }
                 }
             }
         }
@@ -321,7 +333,7 @@ __global__ void k_wtab(const WtabParams p) {
         for (int pos = lane; pos < p.stride; pos += WAVE) {
             p.w[p.D * p.stride + pos] = 0u;
             // lane l of a 16-lane group adds its zeros to tile l: 16 classes, no conflict
-            p.idx[p.D * p.stride + pos] = (uint16_t)(p.gs_log2 == 4 ? (pos >> 2) & 15 : pos % slots);
+            p.idx[p.D * p.stride + pos] = (uint16_t)(p.gs_log2 >= 3 ? (pos >> 2) & 15 : pos % slots);
         }
         if (lane == 0) {
             if (p.meta) p.meta[p.D] = p.fp ? 0u : (uint32_t)TAB_X << 16;
@@ -329,6 +341,50 @@ __global__ void k_wtab(const WtabParams p) {
     }
 }
 
+
+// Exact weight rows for the weights pass (tile_weights VALUES at the reference's precision, entropy_utils.py:124-137):
+// row r = canonical direction canon[r]: every tile with distance < max, in tile order, with its exact FP64 weight
+// ((max - d) / max) ** power — ocml acos / pow on the same fused dot product as everywhere else; weights that underflow
+// to 0.0 stay entries (keys of the reference's dict).  One wave per row, lane = tile.
+struct WexactParams {
+    const double* dir_unit;
+    const int* canon;
+    long R;
+    const double* tiles;
+    int n;
+    double cos_cull;
+    WeightCfg wc;
+    int stride;
+    uint16_t* idx;      // [R][stride]
+    double* w;          // [R][stride]
+    uint32_t* len;      // [R]
+};
+__global__ void k_wexact(const WexactParams p) {
+    const int lane = lane_id();
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long r = wave; r < p.R; r += nwaves) {
+        const long dd = (long)p.canon[r];
+        const double dx = p.dir_unit[3 * dd], dy = p.dir_unit[3 * dd + 1], dz = p.dir_unit[3 * dd + 2];
+        int count = 0;
+        for (int t0 = 0; t0 < p.n; t0 += WAVE) {
+            const int t = t0 + lane;
+            const bool valid = t < p.n;
+            const int ts = valid ? t : 0;
+            const double c = fma(dz, p.tiles[3 * ts + 2], fma(dy, p.tiles[3 * ts + 1], dx * p.tiles[3 * ts]));
+            double wt = 0.0;
+            const bool in = valid && (c > p.cos_cull) && fov_weight_cone(c, p.wc, wt);
+            const unsigned long long mask = __ballot(in);
+            if (in) {
+                const size_t pos = (size_t)r * p.stride + count + below(mask);
+                p.idx[pos] = (uint16_t)t;
+                p.w[pos] = wt;
+            }
+            count += __popcll(mask);
+        }
+        if (lane == 0) p.len[r] = (uint32_t)count;
+    }
+}
 
 // Fused rows: one block-floating-point shift per row = the coarsest of the lattices' own shifts (k_row_stats);
 // delta[k] = the most any row of lattice k loses against its own shift (the lattice's error bound grows by 2^delta)
