@@ -102,3 +102,11 @@ def test_environment_is_read_in_one_place_only():
         assert "experiments/" not in code and "k_spatial_rows" not in code and "k_spatial_walk" not in code, f.name
     mk = (csrc / "Makefile").read_text()
     assert "experiments" not in mk
+    # timing-only switches (VET_EXP_*: wrong results by design) exist for `make VARIANT=...` builds only: they default to 0 and
+    # the product build defines none of them
+    import re
+    lut = (csrc / "vet_spatial_lut.hpp").read_text()
+    for name in set(re.findall(r"VET_EXP_[A-Z_]+", lut)):
+        assert re.search(rf"#ifndef {name}\n#define {name} 0\n#endif", lut), name
+    product_flags = [line for line in mk.splitlines() if line.startswith("CXXFLAGS") and "VFLAGS" not in line]
+    assert product_flags and not any("VET_EXP" in line for line in product_flags)
