@@ -330,6 +330,23 @@ __global__ __launch_bounds__(TRANS_BIG_THREADS) void k_transition_big(const Tran
         const double inv_n = 1.0 / (double)N;
         const bool tab = p.U <= 4096;
         double h = 0.0;
+        // Several passes (an audience spread over many source tiles: the late rows of a long video): every pass scans all
+        // users, so the per-user test must be cheap.  The packed pairs are rewritten once as pass << 24 | source << 12 |
+        // destination (tiles < 4096: TRANS_BIG_MAX_TILES; 0xFF = not in any pass: absent, or the first user of its source
+        // tile) and the scans of steps (2) and (3) read one word per user and touch the LDS for the users of the pass only
+        // (before: a global word, the tile's pass and its first user, per user and scan).  Each thread rewrites and later
+        // reads its own users only: no barrier.
+        const bool multi = passes > 1 && passes < 255;
+        if (multi)
+            for (int u = tid; u < p.U; u += BD) {
+                const unsigned key = pc[u];
+                unsigned v = EMPTY_KEY;
+                if (key != EMPTY_KEY) {
+                    const unsigned src = key >> 16;
+                    if (first_u[src] != (unsigned)u) v = ((unsigned)pass_of[src] << 24) | (src << 12) | (key & 0xFFFu);
+                }
+                pc[u] = v;
+            }
         for (int q = 0; q < passes; ++q) {
             for (int i = tid; i < HS / 4; i += BD) {
                 ((uint4*)hkey)[i] = make_uint4(~0u, ~0u, ~0u, ~0u); ((uint4*)hfu)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -338,10 +355,15 @@ __global__ __launch_bounds__(TRANS_BIG_THREADS) void k_transition_big(const Tran
             __syncthreads();
             // ---- (2) non-first users of the range: bucket insert; the creator counts the bucket into K
             for (int u = tid; u < p.U; u += BD) {
-                const unsigned key = pc[u];
-                if (key == EMPTY_KEY) continue;
-                const unsigned src = key >> 16;
-                if ((int)pass_of[src] != q || first_u[src] == (unsigned)u) continue;
+                unsigned key = pc[u], src;
+                if (multi) {
+                    if ((key >> 24) != (unsigned)q) continue;
+                    key &= 0xFFFFFFu; src = key >> 12;
+                } else {
+                    if (key == EMPTY_KEY) continue;
+                    src = key >> 16;
+                    if (first_u[src] == (unsigned)u) continue;
+                }
                 unsigned slot = (key * 2654435761u) >> hs_shift;
                 for (;;) {
                     const unsigned was = atomicCAS(&hkey[slot], EMPTY_KEY, key);
@@ -355,10 +377,15 @@ __global__ __launch_bounds__(TRANS_BIG_THREADS) void k_transition_big(const Tran
             __syncthreads();
             // ---- (3) the first user of every bucket: latest first appearance per source tile, user << 13 | slot
             for (int u = tid; u < p.U; u += BD) {
-                const unsigned key = pc[u];
-                if (key == EMPTY_KEY) continue;
-                const unsigned src = key >> 16;
-                if ((int)pass_of[src] != q || first_u[src] == (unsigned)u) continue;
+                unsigned key = pc[u], src;
+                if (multi) {
+                    if ((key >> 24) != (unsigned)q) continue;
+                    key &= 0xFFFFFFu; src = key >> 12;
+                } else {
+                    if (key == EMPTY_KEY) continue;
+                    src = key >> 16;
+                    if (first_u[src] == (unsigned)u) continue;
+                }
                 unsigned slot = (key * 2654435761u) >> hs_shift;
                 while (hkey[slot] != key) slot = (slot + 1) & (unsigned)(HS - 1);
                 if (hfu[slot] == (unsigned)u) atomicMax(&last_fu[src], ((unsigned)u << 13) | slot);
