@@ -302,8 +302,9 @@ __device__ __forceinline__ double lattice_entropy_int(int n, V val, double hmax,
 }
 
 // frames fl = wave, wave + NW, ... of the workgroup: K lattices laid end to end in a frame's histogram row
+template <class NOf, class HmaxOf>
 __device__ __forceinline__ void lut_epilogue_int(const unsigned long long* hist, size_t frame_stride, int nf, long f0,
-                                                 int K, const int* n_of, const double* hmax_of, const int* np_of,
+                                                 int K, NOf n_of, HmaxOf hmax_of, const int* np_of,
                                                  double* entropy, int32_t* present, double* weights, int32_t* status) {
     const int NW = blockDim.x >> 6, lane = lane_id(), wv = wave_id();
     const double inv_unit = 1.0 / (4294967296.0 * (double)(1u << TAB_X));
@@ -311,8 +312,8 @@ __device__ __forceinline__ void lut_epilogue_int(const unsigned long long* hist,
         const unsigned long long* hrow = hist + (size_t)fl * frame_stride;
         double total_entropy = 0.0;
         for (int k = 0; k < K; ++k) {
-            const int n = n_of[k];
-            total_entropy += lattice_entropy_int(n, [&](int t) { return hrow[t]; }, hmax_of[k],
+            const int n = n_of(k);
+            total_entropy += lattice_entropy_int(n, [&](int t) { return hrow[t]; }, hmax_of(k),
                                                  (k == 0 && weights) ? weights + (f0 + fl) * (long)n : nullptr, inv_unit);
             hrow += n;
         }
@@ -719,10 +720,10 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
     if (FUSED) {
         lut_epilogue_fused(hist, nf, f0, p.lay, cnt_frame, entropy, present, weights, p.status);
     } else if (!FPT) {
-        int n_of[MAX_LATTICES];
-        double hmax_of[MAX_LATTICES];
-        for (int k = 0; k < p.K; ++k) { n_of[k] = p.lat[k].n; hmax_of[k] = p.lat[k].hmax; }
-        lut_epilogue_int(hist, (size_t)p.n_sum, nf, f0, p.K, n_of, hmax_of, cnt_frame, entropy, present, weights, p.status);
+        // (the lattices' sizes and normalisers straight from the kernel arguments: a uniform index, scalar loads — a
+        // private copy indexed by k would live in scratch memory)
+        lut_epilogue_int(hist, (size_t)p.n_sum, nf, f0, p.K, [&](int k) { return p.lat[k].n; }, [&](int k) { return p.lat[k].hmax; },
+                         cnt_frame, entropy, present, weights, p.status);
     } else
     for (int fl = wv; fl < nf; fl += NW) {
         const unsigned long long* hrow = hist + (size_t)fl * PRIV * p.n_sum;
