@@ -485,6 +485,8 @@ def main():
                                   "tile of every distinct direction of a frame from L2 / Infinity Cache and issues one "
                                   "LDS atomic per entry; see `secondary` for that formulation's own speed of light "
                                   "(DESIGN.md §5)") if (mode == "spatial" and weighted) else
+                                 ("transition mode: bytes are not the limiter (traffic = 1.14 x algorithmic); the per-row LDS "
+                                  "work of the five barrier-separated steps is: see `secondary`") if mode == "transition" else
                                  "integer histogram stream: HBM-bound"},
             "kernel_ms_per_step": {kname: k_ms / args.steps, "k_finalize": fin_ms / args.steps},
             "formulation": formulation,
