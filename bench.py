@@ -154,7 +154,7 @@ def expected_step_ms(workload, mode, strong, world, U, T_total, kernel_ms_max, g
     the kernel (0.142 ms at config 4).
     Strong scaling of transition mode (one video cut into N frame blocks, BASELINE config 5): k_transition_run takes
     9 us + 6.8 us per row of a persistent workgroup (tools/transition_scaling.py) on 8 x 256 workgroup slots, so the
-    kernel of a rank with R/N rows takes 9 + 6.8 * ceil(R / N / 2048) us — 42 us at N = 1, 29 at 2, 16 at 4 and at 8
+    kernel of a rank with R/N rows takes 9 + 6.8 * ceil(R / N / 2048) us — 43 us at N = 1, 29 at 2, 23 at 4, 16 at 8
     (one row per workgroup is the floor) — and the step can never be shorter than the gather: config 5 is too small to
     scale (48.7 us on ONE GPU); it is reported, not tuned for."""
     enqueue_ms = 0.006                                   # host enqueue + stream gaps of a step (1-GPU: step - kernel)

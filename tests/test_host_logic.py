@@ -295,3 +295,21 @@ def test_utilities_export_the_reference_names():
                  "compute_spatial_entropy", "compute_transition_entropy", "calculate_naive_tile_weights",
                  "find_naive_tile_index", "compute_naive_spatial_entropy", "EntropyConfig"):
         assert callable(getattr(u, name)) and name in u.__all__
+
+
+def test_bench_expected_step_model():
+    """The N-GPU step model bench.py prints beside every N > 1 measurement."""
+    import bench
+    # config 5 cut into N frame blocks: 9 us + 6.8 us x ceil(rows per rank / 2048 workgroup slots), never below the gather
+    want = {1: 9 + 6.8 * 5, 2: 9 + 6.8 * 3, 4: 9 + 6.8 * 2, 8: 9 + 6.8 * 1}
+    for n, us in want.items():
+        e = bench.expected_step_ms("config5", "transition", True, n, 512, 10000, 0.0437, 0.010, True)
+        assert abs(e["kernel_ms"] - us * 1e-3) < 1e-9 and e["limiter"] == "kernel"
+        assert abs(e["step_ms"] - (us * 1e-3 + e["enqueue_ms"])) < 1e-12
+    e = bench.expected_step_ms("config5", "transition", True, 8, 512, 10000, 0.0437, 0.040, True)
+    assert e["limiter"] == "gather" and e["step_ms"] == 0.040
+    # one video per rank: the rank's own kernel, the gather hidden behind the next step's kernel (pipelined) or added to it
+    e = bench.expected_step_ms("config4", "spatial", False, 8, 256, 10000, 0.142, 0.030, True)
+    assert e["limiter"] == "kernel" and abs(e["step_ms"] - 0.148) < 1e-9
+    e = bench.expected_step_ms("config4", "spatial", False, 8, 256, 10000, 0.142, 0.030, False)
+    assert abs(e["step_ms"] - 0.178) < 1e-9
