@@ -238,6 +238,50 @@ def test_weight_rows_of_a_resident_result(native, engine, policy):
         np.testing.assert_allclose(eager["weights"][t], hist, rtol=W_RTOL, atol=w_atol(17))
 
 
+def _weights_fallback_worker(q, env):
+    """Child process: weights output and fetched weight rows with / without the exact weight rows (knob read at engine creation)."""
+    import os
+    os.environ.update(env)
+    from viewport_entropy_toolkit import _native
+    eng = _native.Engine(0)
+    out = {}
+    for name, tcs, U, T, policy in (("k2", [100, 20], 70, 40, 1), ("k1", [500], 130, 12, -1)):
+        mu, mv = video(U, T, seed=U + T)
+        plan = _native.Plan(eng, [vo.fibonacci_lattice(tc) for tc in tcs], 120.0, 2.0, True, 100, 200)
+        plan.set_table_policy(policy)
+        eager = plan.spatial(mu=mu, mv=mv, want_weights=True)
+        lazy = plan.spatial_resident(mu=mu, mv=mv)
+        out[name] = (eager["weights"], lazy["result"].rows(1, 3, T - 5), eager["entropy"])
+        plan.close()
+    q.put(out)
+
+
+def test_weights_pass_without_the_exact_rows():
+    """Plans whose exact weight rows do not fit the device run the precise sweep in weights-only mode instead of
+    k_weights_gather (VET_NO_EXACT_ROWS=1 forces that path): the same values (exact weights; the sweep sums strictly in
+    column order, the gather per quarter of the users: the last bits may differ), eager == fetched, entropy untouched."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    res = []
+    for e in ({}, {"VET_NO_EXACT_ROWS": "1"}):
+        q = ctx.Queue()
+        p = ctx.Process(target=_weights_fallback_worker, args=(q, e))
+        p.start()
+        res.append(q.get(timeout=600))
+        p.join(60)
+        assert p.exitcode == 0
+    for name, tcs, U, T in (("k2", [100, 20], 70, 40), ("k1", [500], 130, 12)):
+        a, b = res[0][name], res[1][name]
+        mu, mv = video(U, T, seed=U + T)
+        _, _, weights = vo.spatial_series(mu, mv, 100, 200, tcs, want_weights=True)
+        for r in (a, b):
+            np.testing.assert_allclose(r[0], weights, rtol=W_RTOL, atol=w_atol(U))
+            assert np.array_equal(r[1], r[0][3:T - 2])                       # fetched block == eager rows, either path
+            assert np.array_equal((r[0] > 0) | np.signbit(r[0]), weights > 0)
+        np.testing.assert_allclose(b[0], a[0], rtol=1e-13, atol=0)
+        assert np.array_equal(a[2], b[2], equal_nan=True)
+
+
 def test_heavily_clustered_users(native, engine):
     """Everybody looks at the same few tiles: same-address LDS atomics, buckets with many users."""
     rng = np.random.default_rng(1)

@@ -250,7 +250,7 @@ int ensure_exact_weights(vet_plan* pl, hipStream_t s) {
     if (X.state != 0) return VET_OK;
     vet_ctx* c = pl->ctx;
     const Lattice& L = pl->lat[0];
-    if (!pl->weighted || L.binned || !L.d_tiles) { X.state = -1; return VET_OK; }
+    if (!pl->weighted || L.binned || !L.d_tiles || c->tune.no_exact_rows) { X.state = -1; return VET_OK; }
     int rc = ensure_alias(pl);
     if (rc) return rc;
     const long R = pl->n_rows;
