@@ -50,9 +50,30 @@ for case in cases:
             first = got
         elif not (np.array_equal(got[0], first[0], equal_nan=True) and np.array_equal(got[1], first[1])):
             bad += 1
+    wbad = 0
+    if mode == "spatial" and weighted:
+        # round 5: the weights-only pass (k_weights_gather: a fixed summation order) — the eager weights output over repeats,
+        # and the rows a device-resident result computes on fetch against it
+        wts = torch.empty((T, 2 * (tcs[0] // 2) + 1), dtype=torch.float64, device=dev)
+        wfirst = None
+        for r in range(max(reps // 10, 3)):
+            wts.fill_(-3.0)
+            plan.spatial_device(mu.data_ptr(), mv.data_ptr(), U, T, ent.data_ptr(), d_weights=wts.data_ptr(), d_status=st.data_ptr(), stream=s.cuda_stream)
+            s.synchronize()
+            w = wts.cpu().numpy().copy()
+            if wfirst is None:
+                wfirst = w
+            elif not np.array_equal(w.view(np.uint64), wfirst.view(np.uint64)):
+                wbad += 1
+        lazy = plan.spatial_resident(mu=mu_h, mv=mv_h, check=False)
+        for r0, nr in ((0, min(T, 256)), (T // 2, min(T - T // 2, 300)), (T - 1, 1)):
+            if not np.array_equal(lazy["result"].rows(1, r0, nr).view(np.uint64), wfirst[r0:r0 + nr].view(np.uint64)):
+                wbad += 1
+        lazy["result"].close()
+    bad += wbad
     form = plan.last_formulation(0) if mode == "spatial" and weighted else "-"
     print(f"{mode:10s} U={U:5d} T={T:6d} tcs={tcs} weighted={weighted} {kind:11s} fov={fov:g} power={power:g} form={form:7s} "
-          f"nan_frames={int(np.isnan(first[0]).sum())} repeats={reps} mismatches={bad}", flush=True)
+          f"nan_frames={int(np.isnan(first[0]).sum())} repeats={reps} mismatches={bad} (weights pass: {wbad})", flush=True)
     plan.close()
     assert bad == 0
 print(f"all cases bit-identical over {reps} repeats ({time.perf_counter() - t0:.0f} s)")

@@ -13,6 +13,7 @@ free0, total = torch.cuda.mem_get_info()
 rng = np.random.default_rng(0)
 t0 = time.perf_counter()
 calls = 0
+keep = []
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     tcs = [int(x) for x in rng.choice([3, 20, 50, 100, 200, 500], size=rng.integers(1, 4))]
     weighted = bool(rng.integers(0, 2))
@@ -29,12 +30,25 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
         assert np.isfinite(r["entropy"]).all() or not weighted or True
         plan.transition(mu=mu, mv=mv)
         calls += 2
+        if it % 7 == 3:                                         # round 5: device-resident results (ids + lazily computed weight rows)
+            rr = plan.spatial_resident(mu=mu, mv=mv, check=False)
+            if rr["result"] is not None:
+                rr["result"].rows(1, 0, min(T, 16)); rr["result"].rows(0, T - 1, 1)
+                keep.append(rr["result"])                       # some outlive their plan
+            rt = plan.transition_resident(mu=mu, mv=mv, check=False)
+            if rt["result"] is not None:
+                rt["result"].rows(1, 0, 1); rt["result"].close()
+            calls += 2
         if it % 10 == 0:                                        # batched launches of every mode
             vids = [(mu[: max(2, T // 2)], mv[: max(2, T // 2)]), (mu, mv), (mu[:, : max(1, U // 3)].copy(), mv[:, : max(1, U // 3)].copy())]
             plan.spatial_batch(vids, want_assign=True, check=False)
             plan.transition_batch(vids, want_pairs=True, check=False)
             calls += 2
     plan.close()
+    for res in keep:
+        res.rows(1, 0, 1)                                       # still served after plan.close(): the result shares the plan's tables
+        res.close()
+    keep.clear()
 eng.synchronize()
 free1, _ = torch.cuda.mem_get_info()
 print(f"{calls} calls in {time.perf_counter() - t0:.1f} s; device memory in use changed by {(free0 - free1) / 2**20:.1f} MiB "
