@@ -162,10 +162,11 @@ int64_t vet_plan_n_dirs(const vet_plan *plan);
 int vet_plan_set_table_policy(vet_plan *plan, int policy);
 /* tile_weights VALUES (the d_weights / h_weights outputs and the weight rows of a vet_result; calculate_tile_weights and
  * the accumulation of compute_spatial_entropy, utilities/entropy_utils.py:131-136, 190-192).  Whatever formulation
- * produces the entropy, they are the reference's: exact FP64 weights, summed over the users in column order, by a
- * weights-only pass of the `precise` sweep — only calls that ask for the weights pay for it (config-3 shape: ~37 ms for
- * all 30 000 frames; a vet_result computes the rows of a fetched block, 256 frames ~0.4 ms), and the entropy path is
- * untouched.  on != 0 returns the formulation's own histogram instead (block-floating-point / FP32 / 2^-52 fixed-point
+ * produces the entropy, they are the reference's: exact FP64 weights (ocml acos / pow), summed over the users in column
+ * order (per contiguous quarter of the users, the quarters added in order), by a weights pass of its own: a gather of
+ * exact FP64 weight rows built once per plan on the first request (the `precise` sweep in weights-only mode where those
+ * rows do not fit the device).  Only calls that ask for the weights pay for it (config-3 shape: 2.8 ms for all 30 000
+ * frames; a vet_result computes the rows of a fetched block, 256 frames 0.2 ms), and the entropy path is untouched.  on != 0 returns the formulation's own histogram instead (block-floating-point / FP32 / 2^-52 fixed-point
  * weight sums: at most n_users * 2^-33 of the row's scale off under the table): a diagnostic for the table layouts. */
 int vet_plan_set_raw_weights(vet_plan *plan, int on);
 int vet_plan_table_stride(const vet_plan *plan, int lattice);

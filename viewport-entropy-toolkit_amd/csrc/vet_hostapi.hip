@@ -17,9 +17,9 @@ struct vet_result {
     size_t row_bytes[2] = {0, 0};
     int64_t rows = 0;
     // Weighted spatial results do not store tile_weights: they keep the samples' direction ids [T][U] and the plan's
-    // shared tables, and a fetched block of weight rows is computed by the weights-only pass of the precise sweep —
-    // the reference's values (exact weights, column order) whatever formulation produced the entropy, and 120 MB less
-    // to write on the hot path of BASELINE config 3.
+    // shared tables, and a fetched block of weight rows is computed by the weights pass (k_weights_gather over the exact
+    // FP64 rows of lattice 0; the precise sweep in weights-only mode where those do not fit) — the reference's values
+    // whatever formulation produced the entropy, and 120 MB less to write on the hot path of BASELINE config 3.
     bool lazy_weights = false;
     std::shared_ptr<WeightsCore> core;
     int32_t* d_ids = nullptr;
@@ -68,7 +68,7 @@ static int run_host(vet_plan* pl, bool transition, const double* h_mu, const dou
         bool ok = hipMalloc(&res->d[0], a_bytes ? a_bytes : 8) == hipSuccess;
         if (res->lazy_weights) {
             rc = ensure_exact_weights(pl, s);      // the rows a fetched block gathers (precise sweep if they do not fit)
-            if (rc) { delete res; return rc; }
+            if (rc) { vet_result_free(res); return rc; }
         }
         if (ok && res->lazy_weights) {
             res->core = pl->wcore; res->U = U;

@@ -393,8 +393,9 @@ int resolve_frames(vet_plan* pl, const int* lat_idx, int K, const vet::SampleSrc
     return VET_OK;
 }
 
-// tile_weights of lattice 0, frames [0, T): the precise sweep in weights-only mode (exact ocml weights, FP64 histogram,
-// every tile owned by one wave, users in column order = the reference's own summation order; -0.0 = key with the value 0.0)
+// tile_weights of lattice 0, frames [0, T) — the weights pass: k_weights_gather over the plan's exact FP64 weight rows
+// (vet_weights_pass.hpp), or, where those rows do not exist (too large for the device), the precise sweep in weights-only
+// mode (exact ocml weights per sample, every tile owned by one wave, users in column order).  -0.0 = key with the value 0.0.
 template <bool FROM_IDS>
 int launch_weights_pass(const WeightsCore& w, const vet::SampleSrc& src, int U, int T, double* d_weights, hipStream_t s,
                         vet_ctx* prof) {
@@ -452,33 +453,30 @@ int launch_weights_pass(const WeightsCore& w, const vet::SampleSrc& src, int U, 
 
 template <bool FROM_IDS>
 int launch_spatial_main(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double* d_entropy, int32_t* d_assign,
-                        double* d_weights, double* d_weights_precise, bool* wrote_precise, int32_t* d_present, int32_t* d_status,
-                        hipStream_t s);
+                        double* d_weights, int32_t* d_present, int32_t* d_status, hipStream_t s);
 
 // tile_weights VALUES carry the reference's precision under every formulation (utilities/entropy_utils.py:131-136,
-// 190-192): only the `precise` formulation writes them itself; the table / FP table / integer sweep formulations — whose
-// histograms hold block-floating-point, FP32-rounded or 2^-52 fixed-point weights, good for the ENTROPY contract only —
-// leave the weights output to a weights-only pass of the precise sweep over the same samples (off the hot path: only
-// calls that ask for d_weights pay for it; the drop-in keeps the samples' direction ids and runs it per fetched block).
+// 190-192).  The formulations' histograms hold block-floating-point, FP32-rounded or 2^-52 fixed-point weights, good for
+// the ENTROPY contract only, so on weighted plans the main launch writes no weights at all and the weights output is
+// left to the weights pass over the same samples — ONE producer for every weights output (the eager d_weights and the
+// rows a device-resident result computes per fetched block are the same bits) and off the hot path: only calls that ask
+// for d_weights pay for it.  Unweighted / binned plans count users per tile: integers, exact, written by the main launch.
 template <bool FROM_IDS>
 int launch_spatial(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double* d_entropy, int32_t* d_assign,
                    double* d_weights, int32_t* d_present, int32_t* d_status, hipStream_t s) {
     const bool exact = d_weights && pl->weighted && !pl->lat[0].binned && !pl->raw_weights;
-    bool wrote = false;
-    int rc = launch_spatial_main<FROM_IDS>(pl, src, U, T, d_entropy, d_assign, exact ? nullptr : d_weights,
-                                           exact ? d_weights : nullptr, &wrote, d_present, d_status, s);
-    if (rc || !exact || wrote) return rc;
+    int rc = launch_spatial_main<FROM_IDS>(pl, src, U, T, d_entropy, d_assign, exact ? nullptr : d_weights, d_present, d_status, s);
+    if (rc || !exact) return rc;
     rc = ensure_exact_weights(pl, s);          // first request for weights: the exact rows of lattice 0 (or not, if too large)
     if (rc) return rc;
     return launch_weights_pass<FROM_IDS>(*pl->wcore, src, U, T, d_weights, s, pl->ctx);
 }
 
-// d_weights: written by whatever formulation runs (unweighted / binned plans: integer counts, exact);
-// d_weights_precise: written only if lattice 0 runs the `precise` formulation (*wrote_precise tells)
+// d_weights: the formulation's own histogram of lattice 0 (unweighted / binned plans: the exact integer counts; weighted
+// plans only with vet_plan_set_raw_weights)
 template <bool FROM_IDS>
 int launch_spatial_main(vet_plan* pl, const vet::SampleSrc& src, int U, int T, double* d_entropy, int32_t* d_assign,
-                        double* d_weights, double* d_weights_precise, bool* wrote_precise, int32_t* d_present, int32_t* d_status,
-                        hipStream_t s) {
+                        double* d_weights, int32_t* d_present, int32_t* d_status, hipStream_t s) {
     vet_ctx* c = pl->ctx;
     const int K = (int)pl->lat.size();
     double* ent_k = d_entropy;
@@ -572,7 +570,6 @@ int launch_spatial_main(vet_plan* pl, const vet::SampleSrc& src, int U, int T, d
         p.ent_k = ent_k + (size_t)k * T;
         p.assign = k == 0 ? d_assign : nullptr;
         p.weights = k == 0 ? d_weights : nullptr;
-        if (k == 0 && precise && d_weights_precise) { p.weights = d_weights_precise; *wrote_precise = true; }
         p.present = k == 0 ? d_present : nullptr;
         p.status = k == 0 ? d_status : nullptr;
         p.FPW = g.FPW; p.G = g.G; p.UC = g.UC;
