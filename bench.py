@@ -10,7 +10,10 @@ collective); the per-video entropy series are collected on rank 0 with ONE RCCL 
 step.  Rank 0 prints one JSON line (contract in the task statement) carrying `roofline`
 (dominant kernel, hipEvent-timed on the launch stream inside the timed region) and, at N = 1,
 `cpu_baseline` (the C port of the reference path timed on this box's host cores on a bounded
-sample of the same workload).
+sample of the same workload), and `parity`: after the timed region every rank compares the series
+its timed steps produced with the C port's on the first frames of the same video (indices bit-exact,
+entropy within 1e-6) and runs one golden of the real reference through the HIP path; a violation
+prints no metric line and exits with status 3.
 """
 from __future__ import annotations
 
@@ -99,16 +102,18 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(mu, mv, tcs, mode, weighted, budget_s):
+def cpu_baseline(mu, mv, tcs, mode, weighted, budget_s, W=100, H=200):
     """C port of the reference path (oracle/vet_oracle.c) on a bounded sample of the same workload:
-    one thread (the reference itself is single-threaded Python) and, for the spatial port, OpenMP
-    over the box's core share.  The real reference's own figures (measured in the
-    build container) are quoted next to them."""
+    one thread (the reference itself is single-threaded Python) and OpenMP over the box's core share
+    (spatial: frames; transition: the nearest-tile sweep of the samples, then the rows).  The real
+    reference's own figures (measured in the build container) are quoted next to them.
+    Returns (record, (frames, entropy, indices)): the outputs of the single-thread run are not thrown
+    away, the parity gate compares the engine's series with them."""
     from oracle import c_port
     c_port.load()
     T, U = mu.shape
-    fn = (lambda a, b: c_port.spatial_series(a, b, 100, 200, tcs, use_weight_distribution=weighted)) \
-        if mode == "spatial" else (lambda a, b: c_port.transition_series(a, b, 100, 200, tcs))
+    fn = (lambda a, b: c_port.spatial_series(a, b, W, H, tcs, use_weight_distribution=weighted)[:2]) \
+        if mode == "spatial" else (lambda a, b: c_port.transition_series(a, b, W, H, tcs))
 
     def timed(threads, budget):
         c_port.set_threads(threads)
@@ -118,32 +123,113 @@ def cpu_baseline(mu, mv, tcs, mode, weighted, budget_s):
         dt = time.perf_counter() - t0
         frames = int(max(probe, min(T, probe * budget / max(dt, 1e-6))))
         t0 = time.perf_counter()
-        fn(mu[:frames], mv[:frames])
+        res = fn(mu[:frames], mv[:frames])
         dt = time.perf_counter() - t0
-        return frames, dt
+        return frames, dt, res
 
-    frames, dt = timed(1, budget_s * 0.6)
+    frames, dt, res = timed(1, budget_s * 0.6)
     out = {"value": frames * U / dt, "unit": "samples/s", "cores": 1, "kind": "port",
            "sample": f"first {frames} of {T} frames x {U} users of the same workload, "
                      f"oracle/vet_oracle.c (gcc -O2, scalar FP64), {dt:.1f} s",
            "host_cpus": os.cpu_count(), "cpu_model": _cpu_model(),
            "reference_python": "viewport-entropy-toolkit itself, 1 core of a Xeon 2.1 GHz (BASELINE.md): "
                                "753 samples/s spatial at 51 tiles, 144 pair-samples/s transition at 201 tiles"}
-    if mode == "spatial":
-        aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        # every core this process may use; a GPU box hands a one-GPU job a CPU share (16 cores) of a 256-core host through
-        # its cgroup, where 256 threads only fight each other — both thread counts are timed, the faster one is reported
-        tried = []
-        for share in sorted({min(16, aff), aff}):
-            if share > 1:
-                f2, d2 = timed(share, budget_s * 0.2)
-                tried.append({"value": f2 * U / d2, "unit": "samples/s", "cores": share,
-                              "sample": f"first {f2} frames, OpenMP over frames, {d2:.1f} s"})
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # every core this process may use; a GPU box hands a one-GPU job a CPU share (16 cores) of a 256-core host through
+    # its cgroup, where 256 threads only fight each other — both thread counts are timed, the faster one is reported
+    tried = []
+    for share in sorted({min(16, aff), aff}):
+        if share > 1:
+            f2, d2, _ = timed(share, budget_s * 0.2)
+            tried.append({"value": f2 * U / d2, "unit": "samples/s", "cores": share,
+                          "sample": f"first {f2} frames, OpenMP over "
+                                    f"{'frames' if mode == 'spatial' else 'samples (nearest-tile sweep) and rows'}, {d2:.1f} s"})
+    c_port.set_threads(1)
+    if tried:
+        best = max(tried, key=lambda r: r["value"])
+        out["all_cores"] = dict(best, affinity_cpus=aff, host_cpus=os.cpu_count(), thread_counts_tried=tried)
+    return out, (frames, res[0], res[1])
+
+
+GOLDEN = {"spatial": ("g4_spatial.npz", "w_tc50", [50]), "transition": ("g5_transition.npz", "tc200", [200])}
+
+
+def _max_rel(got, ref):
+    """max |got - ref| / |ref| with nan == nan (a nan on one side only is inf); both exactly 0 count as 0."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    if got.shape != ref.shape:
+        return float("inf")
+    nan_g, nan_r = np.isnan(got), np.isnan(ref)
+    if (nan_g != nan_r).any():
+        return float("inf")
+    ok = ~nan_r
+    if not ok.any():
+        return 0.0
+    den = np.where(ref[ok] == 0.0, 1.0, np.abs(ref[ok]))
+    return float(np.max(np.abs(got[ok] - ref[ok]) / den))
+
+
+def golden_through_hip(eng, mode):
+    """One committed golden of the real reference (tests/golden/, written by oracle/gen_golden.py from the live
+    reference) through the product path in THIS process: the golden's raw tracks -> the product's ingest
+    (_ingest.build_dense) -> the HIP engine -> compared with the reference's own outputs.  Spatial: G4 w_tc50 under both
+    weighted formulations (sweep and table); transition: G5 tc200.  Returns (ok, text, max_rel)."""
+    from viewport_entropy_toolkit import _ingest, _native, _quantiser
+    fname, tag, tcs = GOLDEN[mode]
+    g = np.load(ROOT / "tests" / "golden" / fname, allow_pickle=False)
+    order = [int(str(c)[4:]) for c in g[f"{tag}__columns"]]
+    _, mu, mv = _ingest.build_dense([(g["time_in"][u], g["mu_in"][u], g["mv_in"][u]) for u in order])
+    plan = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in tcs], 120.0, 2.0, True, 100, 200)
+    worst, bad = 0.0, 0
+    try:
+        if mode == "spatial":
+            for policy in (-1, 1):
+                plan.set_table_policy(policy)
+                res = plan.spatial(mu=mu, mv=mv, want_assign=True)
+                bad += int(np.count_nonzero(res["assign"] != g[f"{tag}__assign"]))
+                worst = max(worst, _max_rel(res["entropy"], g[f"{tag}__entropy"]))
+        else:
+            res = plan.transition(mu=mu, mv=mv, want_pairs=True)
+            bad += int(np.count_nonzero(res["pairs"] != g[f"{tag}__pairs"]))
+            worst = max(worst, _max_rel(res["entropy"], g[f"{tag}__entropy"]))
+    finally:
+        plan.close()
+    ok = bad == 0 and worst <= 1e-6
+    name = f"{fname.split('_')[0]}:{tag}"
+    return ok, (f"{name} ok" if ok else f"{name} FAILED ({bad} index mismatches, entropy max rel {worst:.3g})"), worst
+
+
+def parity_gate(eng, mode, tcs, weighted, W, H, mu_h, mv_h, ent_dev, idx_dev, port_out, n_frames):
+    """SURVEY.md §8d 'parity gates in the same run': the series the timed steps produced (still in device memory)
+    against the C port of the reference path on the first frames of the same video — tile indices bit-exact, entropy
+    within 1e-6 relative, nan == nan — plus one golden of the real reference through the HIP path.  `port_out` = the
+    outputs the cpu_baseline leg already computed (frames, entropy, indices); without it the port runs on `n_frames`
+    frames here.  Replaces the per-frame loops of analyzers/spatial_entropy.py:107-164 / transition_entropy.py:107-175."""
+    T = mu_h.shape[0]
+    if port_out is None:
+        from oracle import c_port
+        c_port.load()
         c_port.set_threads(1)
-        if tried:
-            best = max(tried, key=lambda r: r["value"])
-            out["all_cores"] = dict(best, affinity_cpus=aff, host_cpus=os.cpu_count(), thread_counts_tried=tried)
-    return out
+        take = min(T, n_frames + (1 if mode == "transition" else 0))
+        if mode == "spatial":
+            p_ent, p_idx = c_port.spatial_series(mu_h[:take], mv_h[:take], W, H, tcs, use_weight_distribution=weighted)[:2]
+        else:
+            p_ent, p_idx = c_port.transition_series(mu_h[:take], mv_h[:take], W, H, tcs)
+    else:
+        _, p_ent, p_idx = port_out
+    rows = len(p_ent)
+    e = ent_dev[:rows].cpu().numpy()
+    i = idx_dev[:rows].cpu().numpy()
+    mism = int(np.count_nonzero(i != p_idx))
+    rel = _max_rel(e, p_ent)
+    g_ok, g_text, g_rel = golden_through_hip(eng, mode)
+    ok = mism == 0 and rel <= 1e-6 and g_ok
+    return {"ok": bool(ok), "frames": int(rows), "assign_mismatches": mism, "entropy_max_rel": rel, "golden": g_text,
+            "golden_entropy_max_rel": g_rel, "tolerance": {"indices": "bit-exact", "entropy_rel": 1e-6},
+            "against": "oracle/vet_oracle.c (C port of the reference path, pinned by tests/test_oracle_c.py against the "
+                       "reference's goldens) on the first frames of the timed video; the engine's series are the ones the "
+                       "timed steps left in device memory",
+            "indices": "nearest tile of tile_counts[0] per sample" if mode == "spatial" else "(prior, current) tile pairs of tile_counts[0]"}
 
 
 def expected_step_ms(workload, mode, strong, world, U, T_total, kernel_ms_max, gather_ms_max, pipelined):
@@ -194,6 +280,16 @@ def main():
     ap.add_argument("--loop", action="store_true", help="batched workloads: one call per video instead of one launch")
     ap.add_argument("--policy", type=int, default=0, choices=[-1, 0, 1],
                     help="table policy of the plan (include/vet.h): 0 by call size (default), 1 table, -1 sweep")
+    ap.add_argument("--grid", default="100x200", metavar="WxH",
+                    help="pixel grid of the quantiser (AnalyzerConfig.video_width x video_height; default: the reference's "
+                         "100x200 = 20 301 directions; its README example is 200x400)")
+    ap.add_argument("--parity-frames", type=int, default=64,
+                    help="frames of the timed video the parity gate checks against the C port when the cpu_baseline leg "
+                         "(whose larger sample it otherwise reuses) does not run")
+    ap.add_argument("--inject-fault", default="none", choices=["none", "assign", "entropy", "table"],
+                    help="TEST HOOK of the parity gate: corrupt one nearest-tile word / one entropy value of the engine's "
+                         "output after the timed region, or build the engine's plan on a wrong lattice; bench.py must exit non-zero")
+    ap.add_argument("--no-variants", action="store_true", help="skip the nearest-tile / FP64-weights variants (N = 1)")
     ap.add_argument("--shard", default="videos", choices=["videos", "frames"],
                     help="N > 1: one video per GPU (weak scaling, default) or ONE video cut along the frame "
                          "axis with a 1-frame halo in transition mode (strong scaling, BASELINE config 5)")
@@ -233,14 +329,21 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from viewport_entropy_toolkit import _native, _quantiser
+    from viewport_entropy_toolkit import _dist, _native, _quantiser
 
     U, T, tcs, mode, weighted = WORKLOADS[args.workload]
+    try:
+        W, H = (int(v) for v in args.grid.lower().split("x"))
+    except ValueError:
+        raise SystemExit(f"--grid {args.grid!r}: expected WxH")
+    # the lattices the ENGINE is built on: the workload's, unless the parity gate's test hook asks for a wrong table
+    plan_tcs = list(tcs)
+    if args.inject_fault == "table":
+        plan_tcs[0] += 2
     T_total = T
     strong = args.shard == "frames" and world > 1
     if strong:
         # every rank synthesises the same video and keeps its block of rows (+ halo frame)
-        from viewport_entropy_toolkit import _dist
         mu_h, mv_h = synth_video(U, T, args.seed, 0, args.data)
         if mode == "transition":
             r0, r1, f0, f1 = _dist.transition_frame_block(T, rank, world)
@@ -265,9 +368,12 @@ def main():
 
     eng = _native.Engine(dev_index)
     t0 = time.perf_counter()
-    plan = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in tcs], 120.0, 2.0, weighted, 100, 200)
+    plan = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in plan_tcs], 120.0, 2.0, weighted, W, H)
     eng.synchronize()
     plan_ms = (time.perf_counter() - t0) * 1e3
+    # which device every rank's engine computes on (PCI bus id through the C-ABI), gathered on all ranks; under RCCL two
+    # ranks on one device abort the run here, before anything is timed
+    place = _dist.placement(eng)
     if args.policy:
         plan.set_table_policy(args.policy)
     # everything of a step — the engine's kernels, the copy into the gather buffer, the RCCL gather — is
@@ -421,6 +527,36 @@ def main():
     assert int(status.sum().item()) == 0, "engine flagged out-of-range samples or empty frames"
     e_host = (ents[-1] if n_batch > 1 else ent).cpu().numpy()
     assert np.isfinite(e_host).all()
+
+    # ---- parity gate, outside the timed region, on EVERY rank: the series of the timed steps against the
+    # C port on the first frames of this rank's video, and one reference golden through the HIP path
+    chk_ent, chk_idx = (ents[0], idxs[0]) if n_batch > 1 else (ent, idx)
+    chk_mu, chk_mv = (mu_h, mv_h) if (n_batch == 1 or rank == 0) else synth_video(U, T, args.seed, rank * n_batch, args.data)
+    if args.inject_fault == "assign":
+        chk_idx.view(-1)[U * 3 + 5] ^= 1
+    elif args.inject_fault == "entropy":
+        chk_ent[min(7, R - 1)] *= 1.0 + 3e-6
+    cpu_rec, port_out = None, None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu_rec, port_out = cpu_baseline(mu_h, mv_h, tcs, mode, weighted, args.cpu_seconds, W, H)
+    parity = parity_gate(eng, mode, tcs, weighted, W, H, chk_mu, chk_mv, chk_ent, chk_idx, port_out, args.parity_frames)
+    if multi:
+        # one all_reduce joins the ranks' verdicts: [failed, index mismatches, max relative entropy error, frames]
+        flag = torch.tensor([0.0 if parity["ok"] else 1.0, float(parity["assign_mismatches"])], dtype=torch.float64, device=cdev)
+        worst = torch.tensor([parity["entropy_max_rel"], parity["golden_entropy_max_rel"]], dtype=torch.float64, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        parity.update(ok=bool(flag[0].item() == 0), ranks_failed=int(flag[0].item()), assign_mismatches=int(flag[1].item()),
+                      entropy_max_rel=float(worst[0].item()), golden_entropy_max_rel=float(worst[1].item()),
+                      frames_per_rank=parity["frames"], ranks_checked=world)
+    if not parity["ok"]:
+        # a wrong result has no throughput: no metric line, the verdict on stderr, non-zero exit on every rank
+        if rank == 0:
+            print("PARITY GATE FAILED: " + json.dumps(parity), file=sys.stderr, flush=True)
+        plan.close()
+        if multi:
+            dist.destroy_process_group()
+        raise SystemExit(3)
     if pipelined:       # both buffers hold the same series (same input every step)
         assert np.array_equal(ent_bufs[1].cpu().numpy(), e_host, equal_nan=True)
         if rank == 0:
@@ -467,8 +603,8 @@ def main():
             "config": {"workload": f"{args.workload}: {1 if strong else world} video(s) x {U} users x "
                                    f"{T_total if strong else T} frames, "
                                    f"tile_counts={tcs}, {mode}, "
-                                   f"use_weight_distribution={weighted}, fov=120, W=100, H=200",
-                       "users": U, "frames": T_total if strong else T, "tile_counts": tcs, "mode": mode,
+                                   f"use_weight_distribution={weighted}, fov=120, W={W}, H={H}",
+                       "users": U, "frames": T_total if strong else T, "tile_counts": tcs, "mode": mode, "grid": [W, H],
                        "videos_per_gpu": n_batch, "batched_launch": bool(n_batch > 1 and not args.loop), "parallelism": (f"one video cut into {world} frame blocks" if strong
                                        else f"one video per GPU x{world}")},
             "frames_per_s": (T_total if strong else R * world) * n_batch / (ms_per_step * 1e-3),
@@ -493,7 +629,23 @@ def main():
             "plan_build_ms": plan_ms,
             # built inside the plan's first call (before the timed region): k_row_stats + k_wtab + k_dirrec, hipEvents
             "table_build_ms": table_build_ms, "first_call_ms": first_step_ms,
+            "parity": parity,
         }
+        if mode == "spatial" and weighted:
+            # the arithmetic choice, auditable from this line: the proven worst-case |dH|/H of the integer formulations for
+            # EVERY possible frame of this plan (vet_plan_error_bounds, k_row_stats), per lattice; the contract is 1e-6
+            bounds = [plan.error_bounds(k) for k in range(len(tcs))]
+            pick = 0 if form in ("table", "ftable") else 1
+            out["formulation_bound"] = {
+                "formulation": form, "proven_rel_entropy_error": (max(b[pick] for b in bounds) if form in ("table", "sweep") else None),
+                "per_lattice": {"table": [b[0] for b in bounds], "sweep": [b[1] for b in bounds]},
+                "contract": 1e-6, "engine_threshold": 1e-7,
+                "what": "bound on |H_formulation - H_exact| / H_exact over every frame the plan can be given (<= 1024 users for the "
+                        "sweep), computed on the device from the plan's own weight rows; ftable / precise sum FP64 weights instead "
+                        "(ftable: 1.2e-7 by construction)"}
+            if plan.table_rows():
+                out["table"] = {"rows": plan.table_rows(), "stride": plan.table_stride(0), "directions": plan.n_dirs,
+                                "bytes": (plan.table_rows() + 1) * plan.table_stride(0) * 6}
         if per_rank is not None:
             # attribution of a scaling point: per-rank step / kernel / gather times (ms) and their spread
             out["per_rank"] = {"step_ms": per_rank[:, 0].tolist(), "kernel_ms": per_rank[:, 1].tolist(),
@@ -504,6 +656,15 @@ def main():
                                          + (", overlapped with the next step's kernel inside the timed region" if pipelined else ""),
                                "note": "gather_ms is the gather alone (in order, after the timed region); step_ms is each rank's own clock"}
             # what the curve should look like, so that a SCALE point can be judged the moment it exists
+            # placement, attested by every rank's engine context (vet_device_pci_bus_id) and checked before the timed region
+            out["per_rank"].update({
+                "device_pci_bus_id": [r["pci_bus_id"] for r in place["ranks"]],
+                "device_index": [r["device_index"] for r in place["ranks"]],
+                "host": [r["host"] for r in place["ranks"]],
+                "visible_devices": [r["visible_devices"] for r in place["ranks"]],
+                "distinct_devices": place["distinct"], "n_devices": place["n_devices"],
+                "backend": place["backend"], "rccl_version": place["rccl_version"],
+                "torch_device_count": torch.cuda.device_count()})
             out["per_rank"]["expected"] = expected_step_ms(args.workload, mode, strong, world, U, T_total,
                                                             float(per_rank[:, 1].max()), float(per_rank[:, 2].max()), pipelined)
         # besides the HBM figure, say what the run formulation is really bound by
@@ -515,7 +676,7 @@ def main():
                 # DISTINCT direction among its users and issues one 64-bit LDS atomic per entry
                 dirs = plan.read_dirs()
                 _, alias = np.unique(dirs + 0.0, axis=0, return_inverse=True)
-                ids = (mv_h * 200).astype(np.int64) * 101 + (mu_h * 100).astype(np.int64)
+                ids = (mv_h * H).astype(np.int64) * (W + 1) + (mu_h * W).astype(np.int64)
                 rows = np.sort(alias.reshape(-1)[ids], axis=1)
                 distinct = 1 + (np.diff(rows, axis=1) != 0).sum(1)
                 # how many row loads a walk over GROUPS of F consecutive frames could share (distinct rows of a group /
@@ -582,10 +743,10 @@ def main():
                     "reading": "the LDS is busy a third of the kernel: the row's dependent LDS round trips (a wave waits in "
                                "s_waitcnt for half of its life) bound it, not LDS throughput and not bytes"})
             out["roofline"]["secondary"] = sec
-        if world == 1 and mode == "spatial" and weighted and n_batch == 1:
+        if world == 1 and mode == "spatial" and weighted and n_batch == 1 and not args.no_variants:
             # the same video with use_weight_distribution=False (every user counts 1 on its nearest
             # tile): the HBM-streaming formulation of the path, reported beside the headline
-            plan_u = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in tcs], 120.0, 2.0, False, 100, 200)
+            plan_u = _native.Plan(eng, [_quantiser.lattice_xyz(tc) for tc in tcs], 120.0, 2.0, False, W, H)
             torch.cuda.set_stream(run_stream)
             for _ in range(args.warmup):
                 plan_u.spatial_device(mu.data_ptr(), mv.data_ptr(), U, T, ent.data_ptr(), d_assign=idx.data_ptr(),
@@ -610,6 +771,67 @@ def main():
                              "achieved": per_launch / (ku_ms / max(ku_n, 1) * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                              "unit": "GB/s", "frac": per_launch / (ku_ms / max(ku_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                              "avg_kernel_ms": ku_ms / max(ku_n, 1), "launches": ku_n}}
+        if world == 1 and mode == "spatial" and weighted and n_batch == 1 and not args.no_variants:
+            # ---- what the same video costs with FP64 weights (the arithmetic the u32 table replaces), outside the timed region:
+            # (a) exact FP64 weight rows summed per tile (the d_weights output: k_weights, calculate_tile_weights at the
+            #     reference's precision, entropy_utils.py:131-136) on top of the entropy pass;
+            # (b) policy -1: every sample sweeps every tile, weights evaluated in FP64 (acos / pow), no table at all
+            reps = max(1, min(args.steps, 5))
+            n0 = 2 * (tcs[0] // 2) + 1
+            wts = torch.empty((T, n0), dtype=torch.float64, device=dev)
+            ent_w = torch.empty_like(ent)
+
+            def run_w(p):
+                p.spatial_device(mu.data_ptr(), mv.data_ptr(), U, T, ent_w.data_ptr(), d_assign=idx.data_ptr(),
+                                 d_weights=wts.data_ptr(), d_status=status.data_ptr(), stream=stream)
+
+            def run_e(p):
+                p.spatial_device(mu.data_ptr(), mv.data_ptr(), U, T, ent_w.data_ptr(), d_assign=idx.data_ptr(),
+                                 d_status=status.data_ptr(), stream=stream)
+
+            def clock(fn, p):
+                fn(p)                                   # first call: builds what it needs (exact rows: k_wexact)
+                torch.cuda.synchronize()
+                eng.profile_enable(True)
+                eng.profile_reset()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn(p)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / reps
+                km = {k: eng.profile_get(k)[0] / reps for k in ("k_spatial", "k_weights", "k_finalize")}
+                eng.profile_enable(False)
+                return dt, km
+
+            torch.cuda.set_stream(run_stream)
+            dt_w, km_w = clock(run_w, plan)
+            fp64 = {"exact_weight_rows": {
+                "what": "entropy pass as timed + the weights pass: exact FP64 weights (ocml acos / pow) of every in-FoV tile, "
+                        "summed per tile in FP64 (k_weights_gather; d_weights output [frames x tiles] written to HBM)",
+                "ms_per_step": dt_w * 1e3, "value": U * T / dt_w, "unit": "samples/s",
+                "kernel_ms": km_w, "weights_bytes_written": int(T) * n0 * 8}}
+            if len(tcs) == 1:
+                # audit of the arithmetic choice inside this run: the entropy recomputed on the host, in FP64, from those
+                # exact weight sums (first frames) against the series the u32 table produced in the timed steps
+                m = min(T, 256)
+                w = np.abs(wts[:m].cpu().numpy())
+                pr = w / w.sum(axis=1, keepdims=True)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    h = -np.where(pr > 0, pr * np.log2(pr), 0.0).sum(axis=1) / np.log2(n0)
+                fp64["exact_weight_rows"]["entropy_from_fp64_weights_vs_timed_series_max_rel"] = _max_rel(e_host[:m], h)
+                fp64["exact_weight_rows"]["frames_audited"] = m
+            del wts
+            if form != "sweep":
+                plan.set_table_policy(-1)
+                dt_s, km_s = clock(run_e, plan)
+                form_s = plan.last_formulation(0)
+                e_timed = torch.from_numpy(e_host).to(dev)       # (`ent` has been reused by the nearest-tile variant above)
+                d = (ent_w - e_timed).abs() / e_timed.abs().clamp_min(1e-300)
+                fp64["sweep"] = {"what": "policy -1: brute-force sweep, FP64 weights per (sample, tile), 2^-52 fixed-point histogram",
+                                 "formulation": form_s, "ms_per_step": dt_s * 1e3, "value": U * T / dt_s, "unit": "samples/s",
+                                 "kernel_ms": km_s, "entropy_vs_timed_series_max_rel": float(d.max().item())}
+                plan.set_table_policy(args.policy)
+            out["fp64_weights_variant"] = fp64
         if world == 1 and n_batch == 1 and not args.no_api:
             # the drop-in API itself, from host arrays to the result DataFrame (PCIe inclusive; never `value`)
             import tempfile
@@ -617,7 +839,7 @@ def main():
             from viewport_entropy_toolkit.config import EntropyConfig
             with tempfile.TemporaryDirectory() as tmp:
                 cls = SpatialEntropyAnalyzer if mode == "spatial" else TransitionEntropyAnalyzer
-                an = cls(AnalyzerConfig(tile_counts=list(tcs), output_dir=Path(tmp),
+                an = cls(AnalyzerConfig(video_width=W, video_height=H, tile_counts=list(tcs), output_dir=Path(tmp),
                                         entropy_config=EntropyConfig(use_weight_distribution=weighted)))
                 an.load_arrays(np.arange(T, dtype=np.float64) * 0.1, mu_h, mv_h)
                 best = None
@@ -639,8 +861,8 @@ def main():
                             "tile_assignments]; the dict columns stay in device memory until a cell is read",
                     "ms": best * 1e3, "samples_per_s": U * T / best, "first_cell_fetch_ms": fetch_ms, "later_cell_fetch_ms": next_ms,
                     "cell_len": len(cell), "note": "PCIe-inclusive (pageable numpy arrays); not the headline value"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(mu_h, mv_h, tcs, mode, weighted, args.cpu_seconds)
+        if cpu_rec is not None:
+            out["cpu_baseline"] = cpu_rec
         print(json.dumps(out), flush=True)
     plan.close()
     if multi:

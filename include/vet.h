@@ -42,8 +42,9 @@
 extern "C" {
 #endif
 
-#define VET_VERSION 140 /* 0.1.4: tile_weights values at the reference's precision under every formulation
-                           (+ vet_plan_set_raw_weights); batch descriptors in an event-guarded ring */
+#define VET_VERSION 141 /* 0.1.4: tile_weights values at the reference's precision under every formulation
+                           (+ vet_plan_set_raw_weights); batch descriptors in an event-guarded ring;
+                           0.1.4.1: vet_device_pci_bus_id */
 #define VET_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy: the null stream with legacy ordering */
 
 enum {
@@ -67,12 +68,17 @@ int vet_device_count(void);
 int vet_create(int device_id, vet_ctx **out);
 int vet_destroy(vet_ctx *ctx);
 int vet_synchronize(vet_ctx *ctx);
+/* The device a context computes on, as its PCI bus id ("0000:05:00.0"; buf of len >= 16): what a rank of a
+ * multi-GPU job (one process per video, README.md:108-120) reports so that a job can show that its N ranks
+ * sit on N distinct devices (bench.py's per_rank block; _dist refuses two ranks of an RCCL job on one device). */
+int vet_device_pci_bus_id(vet_ctx *ctx, char *buf, int len);
 /* Per-kernel timing with hipEvents on the launch stream (bench.py's roofline leg). */
 int vet_profile_enable(vet_ctx *ctx, int on);
 int vet_profile_reset(vet_ctx *ctx);
 /* kernel ids: 0 k_grid_dirs, 1 k_nearest_lut, 2 k_spatial (any variant), 3 k_transition,
  *             4 k_finalize, 5 k_wtab (direction weight table build),
- *             6 k_weights (weights-only pass of the precise sweep: the d_weights output / fetched weight rows) */
+ *             6 k_weights (the weights pass: k_weights_gather over the plan's exact FP64 weight rows, or the precise sweep in
+ *               weights-only mode where those do not fit: the d_weights output / fetched weight rows) */
 int vet_profile_get(vet_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
 const char *vet_kernel_name(int kernel_id);
 
@@ -163,7 +169,8 @@ int vet_plan_set_table_policy(vet_plan *plan, int policy);
 /* tile_weights VALUES (the d_weights / h_weights outputs and the weight rows of a vet_result; calculate_tile_weights and
  * the accumulation of compute_spatial_entropy, utilities/entropy_utils.py:131-136, 190-192).  Whatever formulation
  * produces the entropy, they are the reference's: exact FP64 weights (ocml acos / pow), summed over the users in column
- * order (per contiguous quarter of the users, the quarters added in order), by a weights pass of its own: a gather of
+ * order within each of NW contiguous shares of the users (NW = 4, 2 or 1 by lattice size and LDS), the shares added in order —
+ * deterministic, within 1e-9 relative of the reference's single sequential sum, not bit-equal to it —, by a weights pass of its own: a gather of
  * exact FP64 weight rows built once per plan on the first request (the `precise` sweep in weights-only mode where those
  * rows do not fit the device).  Only calls that ask for the weights pay for it (config-3 shape: 2.8 ms for all 30 000
  * frames; a vet_result computes the rows of a fetched block, 256 frames 0.2 ms), and the entropy path is untouched.  on != 0 returns the formulation's own histogram instead (block-floating-point / FP32 / 2^-52 fixed-point
@@ -262,9 +269,11 @@ int vet_transition_entropy_host(vet_plan *plan, const double *h_mu, const double
  * entropy only, :216-219).  These variants bring back the entropy series (and the per-frame user counts)
  * and keep assign [T][U] i32 + weights [T][n_0] f64 (transition: pairs [(T-1)][U][2] i32 + srccount
  * [(T-1)][n_0] i32) in device memory owned by a vet_result, from which rows are fetched on demand.
- * Weighted spatial results hold the samples' direction ids [T][U] i32 instead of the weights and compute the weight
- * rows of a fetched block when it is fetched (vet_plan_set_raw_weights: the reference's values, off the hot path).
- * A result handle is returned also with VET_ERR_RANGE / VET_ERR_EMPTY. */
+ * Weighted spatial results hold the samples' direction ids [T][U] i32 instead of the weights when those are not larger
+ * (U * 4 <= n_0 * 8 bytes per frame; otherwise the weight rows are stored) and compute the weight rows of a fetched block
+ * when it is fetched (vet_plan_set_raw_weights: the reference's values, off the hot path; same bits as the eager output).
+ * A result handle is returned also with VET_ERR_RANGE / VET_ERR_EMPTY.  vet_result_fetch may be called from several
+ * threads on one result (fetches of lazily computed weight rows take turns on the result's staging buffer). */
 typedef struct vet_result vet_result;
 int vet_spatial_entropy_host_resident(vet_plan *plan, const double *h_mu, const double *h_mv,
                                       const int32_t *h_ids, int n_users, int n_frames,

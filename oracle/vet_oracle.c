@@ -167,19 +167,24 @@ static double transition_frame(const int *p, const int *c, int N, int n) {
     return ent / mx;
 }
 
-/* nearest tile of every grid direction actually used is computed on the fly (no LUT). */
+/* nearest tile of every grid direction actually used is computed on the fly (no LUT).
+ * With -fopenmp the samples of the nearest-tile sweep and then the rows are spread over the host cores
+ * (every row is the same literal walk, with its own p / c lists); one thread = the plain serial loops.
+ * Error precedence as in the serial walk: an out-of-range sample (-3) is met in the first lattice's
+ * sweep, before any row is looked at; otherwise a row without a common user gives -4. */
 int oracle_transition(const double *mu, const double *mv, int T, int U, int W, int H, const double *grid,
                       int K, const int *n_tiles, const double *const *tiles, double *out_entropy,
                       int32_t *out_pairs) {
     int *tile = (int *)malloc(sizeof(int) * (size_t)T * U);
-    int *p = (int *)malloc(sizeof(int) * U), *c = (int *)malloc(sizeof(int) * U);
     int rc = 0;
     for (int r = 0; r + 1 < T; ++r) out_entropy[r] = 0.0;
     for (int k = 0; k < K && !rc; ++k) {
         const int n = n_tiles[k];
-        for (long i = 0; i < (long)T * U && !rc; ++i) {
+        int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+        for (long i = 0; i < (long)T * U; ++i) {
             const long id = dir_id(mu[i], mv[i], W, H);
-            if (id == -2) { rc = -3; break; }
+            if (id == -2) { bad |= 1; tile[i] = -1; continue; }
             if (id < 0) { tile[i] = -1; continue; }
             double best = 1e300;
             int bi = 0;
@@ -189,21 +194,30 @@ int oracle_transition(const double *mu, const double *mv, int T, int U, int W, i
             }
             tile[i] = bi;
         }
-        for (int r = 0; r + 1 < T && !rc; ++r) {
-            int N = 0;
-            for (int u = 0; u < U; ++u) {
-                const int a = tile[(long)r * U + u], b = tile[(long)(r + 1) * U + u];
-                if (k == 0 && out_pairs) {
-                    out_pairs[((long)r * U + u) * 2] = (a >= 0 && b >= 0) ? a : -1;
-                    out_pairs[((long)r * U + u) * 2 + 1] = (a >= 0 && b >= 0) ? b : -1;
+        if (bad) { rc = -3; break; }
+        int empty = 0;
+#pragma omp parallel reduction(| : empty)
+        {
+            int *p = (int *)malloc(sizeof(int) * U), *c = (int *)malloc(sizeof(int) * U);
+#pragma omp for schedule(static)
+            for (int r = 0; r < T - 1; ++r) {
+                int N = 0;
+                for (int u = 0; u < U; ++u) {
+                    const int a = tile[(long)r * U + u], b = tile[(long)(r + 1) * U + u];
+                    if (k == 0 && out_pairs) {
+                        out_pairs[((long)r * U + u) * 2] = (a >= 0 && b >= 0) ? a : -1;
+                        out_pairs[((long)r * U + u) * 2 + 1] = (a >= 0 && b >= 0) ? b : -1;
+                    }
+                    if (a >= 0 && b >= 0) { p[N] = a; c[N] = b; ++N; }
                 }
-                if (a >= 0 && b >= 0) { p[N] = a; c[N] = b; ++N; }
+                if (N == 0) { empty |= 1; continue; }
+                out_entropy[r] += transition_frame(p, c, N, n);
             }
-            if (N == 0) { rc = -4; break; }
-            out_entropy[r] += transition_frame(p, c, N, n);
+            free(p); free(c);
         }
+        if (empty) rc = -4;
     }
     for (int r = 0; r + 1 < T; ++r) out_entropy[r] /= K;
-    free(tile); free(p); free(c);
+    free(tile);
     return rc;
 }

@@ -96,3 +96,43 @@ def test_shard_arithmetic():
     assert (f0, f1) == (r0, r1 + 1) and r1 - r0 in (1249, 1250)
     # single process: gather_series is the identity
     assert np.array_equal(_dist.gather_series(np.arange(3.0))[0], np.arange(3.0))
+
+
+def test_placement_check():
+    """Two ranks of a one-process-per-GPU job on one device: refused when distinct devices are required (RCCL jobs),
+    reported otherwise (a gloo rehearsal on one device)."""
+    sys.path.insert(0, str(ROOT / "viewport-entropy-toolkit_amd"))
+    from viewport_entropy_toolkit import _dist
+    ok = [{"rank": r, "pci_bus_id": f"0000:{5 + r:02x}:00.0", "host": "n0"} for r in range(8)]
+    s = _dist.check_placement(ok, require_distinct=True)
+    assert s == {"n_ranks": 8, "n_devices": 8, "distinct": True, "shared": {}}
+    stacked = [{"rank": r, "pci_bus_id": "0000:05:00.0", "host": "n0"} for r in range(3)] + [{"rank": 3, "pci_bus_id": "0000:06:00.0", "host": "n0"}]
+    s = _dist.check_placement(stacked, require_distinct=False)
+    assert s["n_devices"] == 2 and not s["distinct"] and s["shared"] == {"n0:0000:05:00.0": [0, 1, 2]}
+    with pytest.raises(_dist.PlacementError, match=r"ranks \[0, 1, 2\]"):
+        _dist.check_placement(stacked, require_distinct=True)
+    # the same bus id on two hosts is two devices
+    two_hosts = [{"rank": 0, "pci_bus_id": "0000:05:00.0", "host": "a"}, {"rank": 1, "pci_bus_id": "0000:05:00.0", "host": "b"}]
+    assert _dist.check_placement(two_hosts, require_distinct=True)["distinct"]
+
+
+def test_default_engine_device_never_falls_back_to_device_0(monkeypatch):
+    """VERDICT r05 weak #4: an out-of-range LOCAL_RANK / VET_DEVICE must raise, not stack the ranks on GPU 0."""
+    sys.path.insert(0, str(ROOT / "viewport-entropy-toolkit_amd"))
+    from viewport_entropy_toolkit import _native
+    pick = _native.Engine.default_device_id
+    monkeypatch.delenv("VET_DEVICE", raising=False)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    assert pick(1) == 0 and pick(8) == 0
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert pick(8) == 3
+    with pytest.raises(_native.NativeUnavailable, match="LOCAL_RANK=3 names no visible device"):
+        pick(1)
+    monkeypatch.setenv("VET_DEVICE", "0")           # VET_DEVICE wins over LOCAL_RANK (a rehearsal of N ranks on one GPU)
+    assert pick(1) == 0
+    monkeypatch.setenv("VET_DEVICE", "-1")
+    with pytest.raises(_native.NativeUnavailable, match="VET_DEVICE=-1"):
+        pick(8)
+    monkeypatch.setenv("VET_DEVICE", "gpu0")
+    with pytest.raises(_native.NativeUnavailable, match="not a device index"):
+        pick(8)

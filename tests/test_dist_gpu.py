@@ -63,9 +63,21 @@ def _worker(rank, world, port, q):
         cut_s = _dist.spatial_frame_sharded(mu, mv, lambda a, b: plan.spatial(mu=a, mv=b, want_assign=False)["entropy"])
         # every rank's share of the videos in ONE batched launch, one gather
         got_b = _dist.analyze_videos_batched(videos, lambda vs: [r["entropy"] for r in plan.spatial_batch(vs)])
+        # placement: both ranks report device 0's PCI id; a job that requires one rank per GPU refuses it on every rank
+        pl = _dist.placement(eng)
+        ok_p = (pl["backend"] == "gloo" and pl["n_devices"] == 1 and not pl["distinct"] and len(pl["ranks"]) == world
+                and pl["ranks"][0]["pci_bus_id"] == pl["ranks"][1]["pci_bus_id"] == eng.pci_bus_id())
+        try:
+            _dist.placement(eng, require_distinct=True)
+            ok_p = False
+        except _dist.PlacementError as e:
+            ok_p = ok_p and "ranks [0, 1]" in str(e)
+        if rank == 1:
+            q.put(("placement", ok_p))
         if rank == 0:
+            ok_t0 = ok_p
             ok_v = set(got) == set(range(len(videos))) and all(np.array_equal(got[v], spatial(videos[v])) for v in got)
-            ok_t = bool(np.array_equal(cut, trans(mu, mv)))
+            ok_t = ok_t0 and bool(np.array_equal(cut, trans(mu, mv)))
             ok_s = bool(np.array_equal(cut_s, plan.spatial(mu=mu, mv=mv, want_assign=False)["entropy"]))
             ok_b = set(got_b) == set(range(len(videos))) and all(np.array_equal(got_b[v], spatial(videos[v])) for v in got_b)
             q.put((ok_v, ok_t and ok_s and ok_b))
@@ -85,7 +97,9 @@ def test_two_ranks_gloo_with_hip_compute():
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
-    ok_v, ok_t = q.get(timeout=10)
+    got = [q.get(timeout=10), q.get(timeout=10)]
+    assert ("placement", True) in got, "rank 1: placement record wrong, or two ranks on one device were not refused"
+    ok_v, ok_t = [g for g in got if g[0] != "placement"][0]
     assert ok_v, "videos sharded over two ranks differ from the one-process result"
     assert ok_t, "frame-sharded transition / spatial entropy or the batched video shares differ from the one-process result"
 
@@ -110,6 +124,9 @@ def _rccl_worker(port, q):
         ok_t = bool(np.array_equal(_dist.transition_frame_sharded(mu, mv, trans), trans(mu, mv)))
         fixed = _dist.gather_series(np.arange(9.0), max_len=9)
         ok_f = len(fixed) == 1 and bool(np.array_equal(fixed[0], np.arange(9.0)))
+        pl = _dist.placement(eng)                    # world 1 under RCCL: a PCI id, the RCCL version, distinct by construction
+        ok_f = ok_f and pl["backend"] == "nccl" and pl["distinct"] and bool(pl["rccl_version"]) \
+            and ":" in pl["ranks"][0]["pci_bus_id"] and pl["ranks"][0]["device_index"] == 0
         q.put((ok_v, ok_t, ok_f))
         plan.close()
     finally:
@@ -197,6 +214,12 @@ def test_bench_launches_its_own_ranks(workload, shard):
     assert len(pr["step_ms"]) == len(pr["kernel_ms"]) == len(pr["gather_ms"]) == 2
     assert all(k > 0 for k in pr["kernel_ms"]) and all(g > 0 for g in pr["gather_ms"])
     assert pr["step_ms_max_over_min"] >= 1.0
+    # the line attests its own placement: the device every rank's engine context ran on, the backend, and whether the
+    # ranks held distinct devices (a gloo rehearsal on a one-GPU box shares device 0 and says so)
+    assert len(pr["device_pci_bus_id"]) == 2 and all(len(d) >= 7 and ":" in d for d in pr["device_pci_bus_id"])
+    assert pr["backend"] == "gloo" and pr["device_index"] == [0, 0]
+    assert pr["distinct_devices"] is False and pr["n_devices"] == 1 and pr["torch_device_count"] >= 1
+    assert rec["parity"]["ok"] and rec["parity"]["ranks_checked"] == 2 and rec["parity"]["assign_mismatches"] == 0
 
 
 @pytest.mark.parametrize("workload", ["config2", "config5"])
@@ -221,6 +244,9 @@ def test_bench_rccl_pipelined_gather(workload):
     assert len(pr["step_ms"]) == 1 and pr["kernel_ms"][0] > 0 and pr["gather_ms"][0] > 0
     assert pr["kernel_ms"][0] <= rec["ms_per_step"] * 1.001          # the kernel is inside the step
     assert rec["roofline"]["measured_copy_ceiling"]["GBps"] > 100       # 3.8 MB at config 2: a launch-bound copy
+    assert pr["backend"] == "nccl" and pr["rccl_version"] and pr["distinct_devices"] is True
+    assert len(pr["device_pci_bus_id"]) == 1 and ":" in pr["device_pci_bus_id"][0]
+    assert rec["parity"]["ok"] and rec["parity"]["ranks_checked"] == 1
 
 
 def _engine_then_torch_worker(q):
@@ -255,3 +281,45 @@ def test_engine_first_then_torch_cuda():
     assert ok_torch and same
     assert len(runtimes) == 1, runtimes
     assert preloaded and runtimes[0] == preloaded
+
+
+def _run_bench(*extra, timeout=600):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "VET_BENCH_BACKEND"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--no-api", "--no-variants",
+                           *extra], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("workload", ["config2", "config5", "config2x64"])
+def test_bench_line_carries_the_parity_gate(workload):
+    """SURVEY.md §8d 'parity gates in the same run': the line bench.py prints holds the comparison of the timed series with
+    the C port of the reference path (indices bit-exact, entropy <= 1e-6) and one reference golden through the HIP path."""
+    out = _run_bench("--workload", workload, "--no-cpu-baseline")
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    par = rec["parity"]
+    assert par["ok"] is True and par["assign_mismatches"] == 0 and par["frames"] >= 63
+    assert 0.0 <= par["entropy_max_rel"] <= 1e-6 and par["golden"].endswith(" ok")
+    assert par["golden"].startswith("g5:tc200" if rec["config"]["mode"] == "transition" else "g4:w_tc50")
+
+
+@pytest.mark.parametrize("fault,workload", [("assign", "config2"), ("entropy", "config2"), ("table", "config2"),
+                                            ("assign", "config5"), ("entropy", "config5"), ("table", "config5")])
+def test_bench_fails_on_a_parity_violation(fault, workload):
+    """One flipped nearest-tile word, one entropy value 3e-6 off, or an engine plan built on the wrong lattice: bench.py prints
+    no metric line and exits non-zero."""
+    out = _run_bench("--workload", workload, "--no-cpu-baseline", "--inject-fault", fault)
+    assert out.returncode == 3, (out.returncode, out.stderr[-1500:])
+    assert "PARITY GATE FAILED" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")], "a metric line was printed for a wrong result"
+
+
+def test_bench_parity_reuses_the_cpu_baseline_sample():
+    """With the cpu_baseline leg on, the gate compares the engine with the outputs that leg computed (its whole sample)."""
+    out = _run_bench("--workload", "config2", "--cpu-seconds", "3")
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["parity"]["ok"] and rec["parity"]["frames"] > 64
+    assert str(rec["parity"]["frames"]) in rec["cpu_baseline"]["sample"]
+    assert rec["cpu_baseline"]["all_cores"]["cores"] > 1

@@ -313,3 +313,41 @@ def test_bench_expected_step_model():
     assert e["limiter"] == "kernel" and abs(e["step_ms"] - 0.148) < 1e-9
     e = bench.expected_step_ms("config4", "spatial", False, 8, 256, 10000, 0.142, 0.030, False)
     assert abs(e["step_ms"] - 0.178) < 1e-9
+
+
+def test_load_arrays_is_the_ingest_step(tmp_path):
+    """ADVICE r04 / VERDICT r05 weak #8: on the array path the range check belongs to the ingest (load_arrays), in the
+    reference's order — 2dmu, 2dmv, dimensions (data_utils.py:322-331) — so an out-of-range sample raises at load time whatever
+    row it sits in, before (and never instead of) the compute-time error of an earlier empty frame."""
+    an = vt.SpatialEntropyAnalyzer(AnalyzerConfig(tile_counts=[20], output_dir=tmp_path / "o"))
+    nan = np.nan
+    t = np.arange(3) * 0.1
+    ok_mu = np.array([[0.5, nan], [nan, nan], [0.25, 1.0]])          # row 1 is an empty frame: a compute-time error
+    bad_mu = ok_mu.copy()
+    bad_mu[2, 0] = 1.5                                               # row 2 is out of range: an ingest error
+    mv = np.full((3, 2), 0.5)
+    with pytest.raises(vt.ValidationError, match="^Normalized coordinates must be between 0 and 1$"):
+        an.load_arrays(t, bad_mu, mv)
+    assert not an._data_cache                                        # nothing was loaded
+    with pytest.raises(vt.ValidationError, match="^Normalized coordinates must be between 0 and 1$"):
+        an.load_arrays(t, ok_mu, np.where(np.isnan(ok_mu), nan, -1e-9))
+    an.load_arrays(t, ok_mu, mv)                                     # NaN (absent), 0.0 and 1.0 are inside the range
+    assert an._data_cache
+    odd = vt.SpatialEntropyAnalyzer(AnalyzerConfig(video_width=101, video_height=200, tile_counts=[20], output_dir=tmp_path / "o"))
+    with pytest.raises(vt.ValidationError):
+        odd.load_arrays(t, ok_mu, mv)                                # validate_video_dimensions: even sizes only
+
+
+def test_bench_parity_helpers():
+    """bench.py's in-run parity gate: the comparison itself."""
+    import bench
+    nan = np.nan
+    assert bench._max_rel([1.0, nan, 0.0], [1.0, nan, 0.0]) == 0.0
+    assert bench._max_rel([1.0 + 2e-6, 2.0], [1.0, 2.0]) == pytest.approx(2e-6, rel=1e-6)
+    assert bench._max_rel([1.0, nan], [1.0, 2.0]) == float("inf")            # nan on one side only
+    assert bench._max_rel([1.0], [1.0, 2.0]) == float("inf")                 # shape mismatch
+    assert bench._max_rel([nan], [nan]) == 0.0
+    assert set(bench.GOLDEN) == {"spatial", "transition"}
+    for fname, tag, tcs in bench.GOLDEN.values():
+        g = np.load(bench.ROOT / "tests" / "golden" / fname, allow_pickle=False)
+        assert f"{tag}__entropy" in g.files and f"{tag}__columns" in g.files

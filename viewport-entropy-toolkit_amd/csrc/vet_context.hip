@@ -213,6 +213,12 @@ int vet_create(int device_id, vet_ctx** out) {
     return VET_OK;
 }
 
+int vet_device_pci_bus_id(vet_ctx* c, char* buf, int len) {
+    if (!c || !buf || len < 16) return fail(VET_ERR_INVALID, "ctx or buf is NULL, or len < 16");
+    HIP_TRY(hipDeviceGetPCIBusId(buf, len, c->device));
+    return VET_OK;
+}
+
 int vet_destroy(vet_ctx* c) {
     if (!c) return VET_OK;
     (void)hipSetDevice(c->device);

@@ -61,7 +61,10 @@ struct WeightsCore {
     // direction holding the tile and the exact FP64 weight of every tile with distance < fov/2 — zero-valued keys included.
     // The weights pass then gathers rows (k_weights_gather) instead of sweeping every tile with acos / pow per sample.
     struct Exact {
-        int state = 0;                 // 0 not built, 1 ready, -1 not usable (too large for the device): precise sweep instead
+        int state = 0;                 // 0 not decided, 1 ready, -1 not usable (too large for the device, or no memory at the
+                                       // first request): precise sweep instead.  Decided once (ensure_exact_weights, on the
+                                       // plan's single thread) and never changed afterwards: results that share this core
+                                       // read it from other threads
         int stride = 0, n_rows = 0;
         std::shared_ptr<void> alias;   // [n_dirs] u32  direction -> row | mirrored << 31
         std::shared_ptr<void> idx;     // [n_rows][stride] u16 tiles

@@ -3,6 +3,7 @@
 // No kernels of its own and no CPU compute path.
 #include "vet_host.hpp"
 
+#include <mutex>
 #include <vector>
 
 using namespace vh;
@@ -16,16 +17,21 @@ struct vet_result {
     void* d[2] = {nullptr, nullptr};     // 0: assign / pairs, 1: weights / srccount (null when the weights are lazy)
     size_t row_bytes[2] = {0, 0};
     int64_t rows = 0;
-    // Weighted spatial results do not store tile_weights: they keep the samples' direction ids [T][U] and the plan's
-    // shared tables, and a fetched block of weight rows is computed by the weights pass (k_weights_gather over the exact
-    // FP64 rows of lattice 0; the precise sweep in weights-only mode where those do not fit) — the reference's values
-    // whatever formulation produced the entropy, and 120 MB less to write on the hot path of BASELINE config 3.
+    // Weighted spatial results whose direction ids [T][U] i32 are not larger than the weight rows [T][n_0] f64 do not store
+    // tile_weights: they keep the ids and the plan's shared tables, and a fetched block of weight rows is computed by the
+    // weights pass (k_weights_gather over the exact FP64 rows of lattice 0; the precise sweep in weights-only mode where
+    // those do not fit) — the reference's values whatever formulation produced the entropy, and no 120 MB weights pass on
+    // the hot path of BASELINE config 3 (1024 users, 501 tiles: the two footprints are equal).  Audiences with
+    // U * 4 > n_0 * 8 (9000 users on 51 tiles: ids would be 88 x the weights) store the weight rows instead.
+    // The weights path (exact rows or precise sweep) was decided once for the plan before the result was created
+    // (ensure_exact_weights never revisits it), and `core` is immutable from then on: eager == fetched, same bits.
     bool lazy_weights = false;
     std::shared_ptr<WeightsCore> core;
     int32_t* d_ids = nullptr;
     int U = 0;
     void* d_tmp = nullptr;               // grow-only staging of the fetched weight rows
     size_t tmp_cap = 0;
+    std::mutex fetch_mu;                 // d_tmp is one buffer: concurrent fetches of one result take turns
 };
 
 static int run_host(vet_plan* pl, bool transition, const double* h_mu, const double* h_mv, const int32_t* h_ids,
@@ -64,7 +70,8 @@ static int run_host(vet_plan* pl, bool transition, const double* h_mu, const dou
         res->rows = R > 0 ? R : 0;
         res->row_bytes[0] = transition ? (size_t)U * 2 * 4 : (size_t)U * 4;
         res->row_bytes[1] = transition ? (size_t)n0 * 4 : (size_t)n0 * 8;
-        res->lazy_weights = !transition && pl->weighted && !pl->lat[0].binned && !pl->raw_weights;
+        res->lazy_weights = !transition && pl->weighted && !pl->lat[0].binned && !pl->raw_weights &&
+                            (size_t)U * 4 <= (size_t)n0 * 8;
         bool ok = hipMalloc(&res->d[0], a_bytes ? a_bytes : 8) == hipSuccess;
         if (res->lazy_weights) {
             rc = ensure_exact_weights(pl, s);      // the rows a fetched block gathers (precise sweep if they do not fit)
@@ -151,6 +158,7 @@ int vet_result_fetch(vet_result* r, int which, int64_t row0, int64_t n_rows, voi
         // tile_weights rows [row0, row0 + n_rows): computed now, from the resident direction ids (null stream: the
         // call that made the result has synchronised its stream, and the result may have outlived its context)
         const size_t bytes = (size_t)n_rows * r->row_bytes[1];
+        std::lock_guard<std::mutex> lock(r->fetch_mu);
         if (r->tmp_cap < bytes) {
             if (r->d_tmp) { HIP_TRY(hipFree(r->d_tmp)); r->d_tmp = nullptr; r->tmp_cap = 0; }
             HIP_TRY(hipMalloc(&r->d_tmp, bytes));

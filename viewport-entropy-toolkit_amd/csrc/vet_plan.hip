@@ -267,6 +267,7 @@ int ensure_exact_weights(vet_plan* pl, hipStream_t s) {
     p.maxcount = (int*)d_max.p; p.gs_log2 = -1;
     const int blocks = grid_for(R * vet::WAVE, 256, c->n_cu * 2);
     hipLaunchKernelGGL(vet::k_wtab<false>, dim3(blocks), dim3(256), 0, s, p);       // longest row (conservative cone test)
+    HIP_TRY(hipGetLastError());
     int longest = 0;
     HIP_TRY(hipMemcpyAsync(&longest, d_max.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -282,7 +283,10 @@ int ensure_exact_weights(vet_plan* pl, hipStream_t s) {
         return std::shared_ptr<void>(q, dev_free);
     };
     auto alias = dev_alloc(D * 4), idx = dev_alloc(entries * 2), w = dev_alloc(entries * 8), len = dev_alloc((size_t)R * 4);
-    if (!alias || !idx || !w || !len) return VET_OK;      // out of memory today: the precise sweep serves, a later call retries
+    // out of memory at the first request: decided ONCE for the plan, like "does not fit" above — the precise sweep serves
+    // every later weights request and every result of this plan (a retry that succeeded later would switch paths between an
+    // eager weights call and the fetch of the same frames: same values, different last bits)
+    if (!alias || !idx || !w || !len) { X.state = -1; return VET_OK; }
     HIP_TRY(hipMemcpyAsync(alias.get(), pl->d_alias, D * 4, hipMemcpyDeviceToDevice, s));
     vet::WexactParams q{};
     q.dir_unit = pl->d_dir_unit; q.canon = pl->d_canon; q.R = R; q.tiles = L.d_tiles; q.n = L.n;

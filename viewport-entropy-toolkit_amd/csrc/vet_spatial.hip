@@ -84,6 +84,9 @@ const void* spatial_w_kernel(int wmode, int R, bool precise = false) {
 #ifndef VET_FUSED_UN
 #define VET_FUSED_UN 4
 #endif
+// k_spatial_lut<FUSED, UN == 2> IS the narrow (8-lane rows) kernel: the row width of the class-dealt layout is inferred from
+// UN there (GSL_IL), so the 16-lane fused kernel must not be built with two rows in flight
+static_assert(VET_FUSED_UN != 2, "VET_FUSED_UN=2 would alias the 16-lane fused kernel onto the 8-lane (narrow) instantiation");
 template <bool FROM_IDS>
 const void* lut_kernel_fused(bool il, bool occ8, bool dedup, bool narrow = false) {
     // narrow: rows of 8-lane groups (32-entry blocks; fused rows of 65..96 entries fill three of them instead of two half-empty

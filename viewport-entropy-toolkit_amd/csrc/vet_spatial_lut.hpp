@@ -7,16 +7,6 @@
 #ifndef VET_STAGE_CYCLES
 #define VET_STAGE_CYCLES 0
 #endif
-// Timing-only experiments (WRONG results; never in the product build, see csrc/Makefile VARIANT): what a table row of fewer
-// cache lines could buy at best.  VET_EXP_SYNTH_IDX: the tile indices are not loaded but synthesised from the lane (a
-// row = its 4-byte weights only: 4 lines instead of 6 at 501 tiles — the per-row bitmap format with a FREE decode);
-// VET_EXP_EXTRA_VALU = k: k more dependent VALU operations per entry (what a real decode would add).
-#ifndef VET_EXP_SYNTH_IDX
-#define VET_EXP_SYNTH_IDX 0
-#endif
-#ifndef VET_EXP_EXTRA_VALU
-#define VET_EXP_EXTRA_VALU 0
-#endif
 
 namespace vet {
 
@@ -141,25 +131,7 @@ __device__ __forceinline__ void walk_rows(const uint32_t* frows, const uint32_t*
 #pragma unroll
             for (int k = 0; k < UN; ++k) {
                 w[k] = *(const uint4*)(tab_w + r[k]);
-#if VET_EXP_SYNTH_IDX
-                // conflict-free like the class-dealt rows: component c of the 16 lanes of a row = 16 consecutive tiles
-                // (8-lane rows: the two rows of a hardware group take complementary halves of the 16 classes)
-                const unsigned short t0 = (unsigned short)((eb + sl + 8 * (sub & 1) + 64 * k) % (n - 64));
-                t[k] = make_ushort4(t0, (unsigned short)(t0 + 16), (unsigned short)(t0 + 32), (unsigned short)(t0 + 48));
-#else
                 t[k] = *(const ushort4*)(tab_i + r[k]);
-#endif
-#if VET_EXP_EXTRA_VALU
-                {   // dependent integer operations on the loaded words (rotate-xor chains the compiler cannot fold)
-                    uint32_t a = w[k].x, b = w[k].y, c = w[k].z, d = w[k].w;
-#pragma unroll
-                    for (int e = 0; e < VET_EXP_EXTRA_VALU; ++e) {
-                        a = __builtin_amdgcn_alignbit(a, a, 7) ^ b; b = __builtin_amdgcn_alignbit(b, b, 9) ^ c;
-                        c = __builtin_amdgcn_alignbit(c, c, 11) ^ d; d = __builtin_amdgcn_alignbit(d, d, 13) ^ a;
-                    }
-                    w[k] = make_uint4(a, b, c, d);
-                }
-#endif
             }
 #pragma unroll
             for (int k = 0; k < UN; ++k) {

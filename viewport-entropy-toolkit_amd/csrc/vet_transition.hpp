@@ -363,6 +363,9 @@ __global__ __launch_bounds__(TRANS_BIG_THREADS) void k_transition_big(const Tran
                     if (key == EMPTY_KEY) continue;
                     src = key >> 16;
                     if (first_u[src] == (unsigned)u) continue;
+                    // >= 255 passes (unreachable under the host's limits U < 2^19, n <= 2800: at most 248; kept so that the
+                    // kernel is right by itself): the packed form has no room for the pass, test the tile's pass here
+                    if (passes > 1 && (int)pass_of[src] != q) continue;
                 }
                 unsigned slot = (key * 2654435761u) >> hs_shift;
                 for (;;) {
@@ -385,6 +388,9 @@ __global__ __launch_bounds__(TRANS_BIG_THREADS) void k_transition_big(const Tran
                     if (key == EMPTY_KEY) continue;
                     src = key >> 16;
                     if (first_u[src] == (unsigned)u) continue;
+                    // >= 255 passes (unreachable under the host's limits U < 2^19, n <= 2800: at most 248; kept so that the
+                    // kernel is right by itself): the packed form has no room for the pass, test the tile's pass here
+                    if (passes > 1 && (int)pass_of[src] != q) continue;
                 }
                 unsigned slot = (key * 2654435761u) >> hs_shift;
                 while (hkey[slot] != key) slot = (slot + 1) & (unsigned)(HS - 1);

@@ -44,6 +44,58 @@ def transition_frame_block(n_frames: int, rank: int, world: int) -> Tuple[int, i
     return r0, r1, r0, (r1 + 1 if r1 > r0 else r0)
 
 
+class PlacementError(RuntimeError):
+    """Two ranks of a one-process-per-GPU job compute on the same device."""
+
+
+def check_placement(records: Sequence[dict], require_distinct: bool) -> dict:
+    """``records``: one dict per rank with at least ``rank`` and ``pci_bus_id`` (+ ``host``).  Returns the summary a job
+    prints (ranks per device, whether all devices are distinct); raises ``PlacementError`` naming the ranks that share
+    a device when ``require_distinct`` (RCCL jobs: one rank per GPU is the whole point of the scale-out,
+    README.md:108-120 of the reference runs one process per video)."""
+    by_dev = {}
+    for r in records:
+        by_dev.setdefault((r.get("host", ""), r["pci_bus_id"]), []).append(int(r["rank"]))
+    shared = {f"{h}:{d}" if h else d: ranks for (h, d), ranks in by_dev.items() if len(ranks) > 1}
+    if shared and require_distinct:
+        raise PlacementError(
+            "ranks share a GPU: " + "; ".join(f"device {d} <- ranks {ranks}" for d, ranks in sorted(shared.items()))
+            + " (one process per GPU expected: check LOCAL_RANK / HIP_VISIBLE_DEVICES of the launcher)")
+    return {"n_ranks": len(records), "n_devices": len(by_dev), "distinct": not shared, "shared": shared}
+
+
+def placement(engine, require_distinct: Optional[bool] = None) -> dict:
+    """Which device every rank's engine context computes on, gathered on ALL ranks (one ``all_gather_object`` outside
+    any timed region): ``{"ranks": [{rank, device_index, pci_bus_id, host, visible_devices}], "backend", "rccl_version",
+    "n_devices", "distinct"}``.  Under the ``nccl`` (= RCCL) backend two ranks on one device raise ``PlacementError`` on
+    every rank (``require_distinct`` overrides; a gloo rehearsal on one device may share it)."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    lib = engine.lib
+    mine = {"rank": 0, "device_index": int(engine.device_id), "pci_bus_id": engine.pci_bus_id(),
+            "host": socket.gethostname(), "visible_devices": int(lib.vet_device_count())}
+    backend, version = None, None
+    if dist.is_available() and dist.is_initialized():
+        mine["rank"] = dist.get_rank()
+        backend = dist.get_backend()
+        records = [None] * dist.get_world_size()
+        dist.all_gather_object(records, mine)
+    else:
+        records = [mine]
+    if backend == "nccl":
+        try:
+            version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            version = "unknown"
+    if require_distinct is None:
+        require_distinct = backend == "nccl"
+    summary = check_placement(records, require_distinct)
+    return dict(summary, ranks=sorted(records, key=lambda r: r["rank"]), backend=backend, rccl_version=version)
+
+
 def gather_series(series: np.ndarray, dst: int = 0, max_len: Optional[int] = None, device=None):
     """ONE gather of every rank's 1-D float64 series to ``dst`` (through the process group's backend
     whenever one is initialised, also for a world of one rank).
@@ -175,8 +227,13 @@ def analyze_directories(directories: Sequence, config=None, mode: str = "spatial
     entropy series to ONE gather per round.  Returns ``{directory index: entropy[T]}`` on ``dst``."""
     from . import SpatialEntropyAnalyzer, TransitionEntropyAnalyzer
 
+    import torch.distributed as dist
+
     cls = {"spatial": SpatialEntropyAnalyzer, "transition": TransitionEntropyAnalyzer}[mode]
     analyzer = cls(config)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        from . import _native
+        placement(_native.Engine.default())       # raises PlacementError under RCCL if two ranks share a GPU
 
     def compute(directory):
         analyzer.process_directory(directory)

@@ -34,13 +34,21 @@ def check_video_dimensions(width: int, height: int) -> None:
         raise ValidationError("Video dimensions must be even numbers")
 
 
+def check_normalized(normalized: np.ndarray, dimension: int) -> None:
+    """The two checks of normalize_to_pixel (data_utils.py:256-259) without the conversion; NaN passes (it compares
+    False on both sides, as in the reference)."""
+    normalized = np.asarray(normalized)
+    with np.errstate(invalid="ignore"):
+        if np.any((normalized < 0) | (normalized > 1)):
+            raise ValidationError("Normalized coordinates must be between 0 and 1")
+    if dimension <= 0:
+        raise ValidationError("Dimension must be positive")
+
+
 def to_pixels(normalized: np.ndarray, dimension: int) -> np.ndarray:
     """(v * dimension) truncated to int; v must lie in [0, 1]."""
     normalized = np.asarray(normalized)
-    if np.any((normalized < 0) | (normalized > 1)):
-        raise ValidationError("Normalized coordinates must be between 0 and 1")
-    if dimension <= 0:
-        raise ValidationError("Dimension must be positive")
+    check_normalized(normalized, dimension)
     return (normalized * dimension).astype(int)
 
 

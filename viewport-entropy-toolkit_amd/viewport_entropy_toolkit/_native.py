@@ -75,6 +75,7 @@ SIGNATURES = {
     "vet_create": (_I, [_I, C.POINTER(_P)]),
     "vet_destroy": (_I, [_P]),
     "vet_synchronize": (_I, [_P]),
+    "vet_device_pci_bus_id": (_I, [_P, C.c_char_p, _I]),
     "vet_profile_enable": (_I, [_P, _I]),
     "vet_profile_reset": (_I, [_P]),
     "vet_profile_get": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_I64)]),
@@ -234,14 +235,41 @@ class Engine:
         self.handle = h
         self.device_id = device_id
 
+    @staticmethod
+    def default_device_id(n_devices: int) -> int:
+        """Device of the per-process default engine: ``VET_DEVICE``, else ``LOCAL_RANK`` (one process per GPU), else 0.
+        A value that names no visible device RAISES: falling back to device 0 would silently stack the ranks of a
+        multi-GPU job on one GPU."""
+        for var in ("VET_DEVICE", "LOCAL_RANK"):
+            raw = os.environ.get(var)
+            if raw is None:
+                continue
+            try:
+                dev = int(raw)
+            except ValueError:
+                raise NativeUnavailable(f"{var}={raw!r} is not a device index") from None
+            if not 0 <= dev < n_devices:
+                raise NativeUnavailable(
+                    f"{var}={dev} names no visible device ({n_devices} visible): refusing to fall back to device 0 "
+                    "(the ranks of a multi-GPU job would share one GPU); fix the launcher's device visibility or set VET_DEVICE")
+            return dev
+        return 0
+
     @classmethod
     def default(cls) -> "Engine":
         with cls._default_lock:
             if cls._default is None:
-                dev = int(os.environ.get("VET_DEVICE", os.environ.get("LOCAL_RANK", "0")))
                 n = load_library().vet_device_count()
-                cls._default = cls(dev if 0 <= dev < max(n, 1) else 0)
+                if n <= 0:
+                    raise NativeUnavailable("no HIP device available; this package has no CPU compute path")
+                cls._default = cls(cls.default_device_id(n))
             return cls._default
+
+    def pci_bus_id(self) -> str:
+        """PCI bus id of the device this context computes on (include/vet.h: vet_device_pci_bus_id)."""
+        buf = C.create_string_buffer(64)
+        _check(self.lib, self.lib.vet_device_pci_bus_id(self.handle, buf, 64))
+        return buf.value.decode()
 
     def close(self):
         if getattr(self, "handle", None):

@@ -112,11 +112,19 @@ class _EntropyAnalyzerBase:
 
     def load_arrays(self, frame_times: np.ndarray, mu: np.ndarray, mv: np.ndarray,
                     user_names: Optional[List[str]] = None) -> None:
-        """Engine-native ingest: dense frame-major arrays (NaN = absent) instead of CSV files."""
+        """Engine-native ingest: dense frame-major arrays (NaN = absent) instead of CSV files.
+
+        This IS the ingest step, so the ingest's checks are made here and in the reference's order
+        (process_viewport_data, data_utils.py:322-331: 2dmu range, 2dmv range, video dimensions): a sample outside
+        [0, 1] raises ``ValidationError`` now, as ``process_directory`` would, and never competes with a compute-time
+        error (an empty frame) of ``compute_entropy`` — whichever row either sits in."""
         mu = np.ascontiguousarray(mu, dtype=np.float64)
         mv = np.ascontiguousarray(mv, dtype=np.float64)
         if mu.ndim != 2 or mu.shape != mv.shape or len(frame_times) != mu.shape[0]:
             raise ValidationError("frame_times[T], mu[T,U], mv[T,U] expected")
+        _ingest.check_normalized(mu, self.config.video_width)       # NaN = absent passes
+        _ingest.check_normalized(mv, self.config.video_height)
+        _ingest.check_video_dimensions(self.config.video_width, self.config.video_height)
         names = list(user_names) if user_names is not None else [f"user{u:03d}" for u in range(mu.shape[1])]
         self._dense = (np.asarray(frame_times, dtype=np.float64), mu, mv, names)
         self._data_cache = {"dense": True}
