@@ -238,6 +238,53 @@ def test_weight_rows_of_a_resident_result(native, engine, policy):
         np.testing.assert_allclose(eager["weights"][t], hist, rtol=W_RTOL, atol=w_atol(17))
 
 
+def test_resident_result_fetched_from_two_threads(native, engine):
+    """a lazily computed block of weight rows is staged in ONE buffer per result; two host threads reading
+    different blocks of the same result (two cells of one DataFrame) take turns on it and both get the eager bits."""
+    import threading
+    mu, mv = video(48, 400, seed=31)
+    plan = plan_for(native, engine, [100], policy=1)
+    eager = plan.spatial(mu=mu, mv=mv, want_weights=True)
+    res = plan.spatial_resident(mu=mu, mv=mv)["result"]
+    errors = []
+
+    def reader(offset):
+        try:
+            for it in range(60):
+                r0 = (offset + 37 * it) % 380
+                n = 1 + (it * 7 + offset) % 20                       # blocks of different sizes: the staging buffer regrows
+                if not np.array_equal(res.rows(1, r0, n), eager["weights"][r0:r0 + n]):
+                    errors.append(("weights", offset, r0, n))
+                if not np.array_equal(res.rows(0, r0, n), eager["assign"][r0:r0 + n]):
+                    errors.append(("assign", offset, r0, n))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=reader, args=(o,)) for o in (0, 11, 23)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors[:3]
+    res.close()
+    plan.close()
+
+
+def test_resident_result_stores_weights_for_wide_audiences(native, engine):
+    """ADVICE r05: direction ids [T][U] i32 are kept instead of the weight rows [T][n_0] f64 only when they are not larger;
+    900 users on 21 tiles store the weight rows (the ids would be 21 x their size) — same bits as the eager output either way."""
+    mu, mv = video(900, 12, seed=5)
+    plan = plan_for(native, engine, [20], policy=1)
+    eager = plan.spatial(mu=mu, mv=mv, want_weights=True)
+    lazy = plan.spatial_resident(mu=mu, mv=mv)
+    assert np.array_equal(lazy["result"].rows(1, 0, 12), eager["weights"])
+    assert np.array_equal(lazy["result"].rows(1, 5, 3), eager["weights"][5:8])
+    assert np.array_equal(lazy["result"].rows(0, 0, 12), eager["assign"])
+    _, _, weights = vo.spatial_series(mu, mv, 100, 200, [20], want_weights=True)
+    np.testing.assert_allclose(eager["weights"], weights, rtol=W_RTOL, atol=w_atol(900))
+    plan.close()
+
+
 def _weights_fallback_worker(q, env):
     """Child process: weights output and fetched weight rows with / without the exact weight rows (knob read at engine creation)."""
     import os

@@ -7,7 +7,7 @@ for w in $2; do
   for r in $(seq $reps); do
     for kv in $1; do
       printf "%-10s %-22s " "$w" "$kv"
-      env $kv python3 tools/kt.py --workload $w
+      env ${kv//,/ } python3 tools/kt.py --workload $w     # VAR=a,VAR2=b sets several
     done
   done
 done

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"
 W=$1; TAG=$2
 mkdir -p gpurun_out/$TAG
-run() { timeout -k 10 150 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/$TAG/$1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-api --workload $W > gpurun_out/$TAG/$1.log 2>&1 || { echo "pass $1 failed"; return 1; }; echo "pass $1 ok"; }
+run() { timeout -k 10 150 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/$TAG/$1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-api --no-variants $BENCH_EXTRA --workload $W > gpurun_out/$TAG/$1.log 2>&1 || { echo "pass $1 failed"; return 1; }; echo "pass $1 ok"; }
 run TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum || exit 1
 run TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum TCP_GATE_EN2_sum || exit 1
 run TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TD_TC_STALL_sum TD_SPI_STALL_sum || exit 1

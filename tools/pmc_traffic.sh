@@ -12,9 +12,9 @@ TAG=$1; shift
 mkdir -p gpurun_out/$TAG
 for W in "$@"; do
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 150 rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/$TAG/$W/$C -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-api --workload $W > gpurun_out/$TAG/$W.$C.log 2>&1
+    timeout -k 10 150 rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/$TAG/$W/$C -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-api --no-variants $BENCH_EXTRA --workload $W > gpurun_out/$TAG/$W.$C.log 2>&1
   done
-  timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/$W/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-api --workload $W > gpurun_out/$TAG/$W.trace.log 2>&1
+  timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/$W/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-api --no-variants $BENCH_EXTRA --workload $W > gpurun_out/$TAG/$W.trace.log 2>&1
   echo "pmc passes of $W done"
 done
 python3 tools/pmc_traffic.py gpurun_out/$TAG "$@"

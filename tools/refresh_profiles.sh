@@ -36,7 +36,7 @@ for w in config4 defaults config2x64; do VET_NO_FUSED=1 line ${w}_per_lattice_ta
 timeout -k 10 300 python3 tools/precise_timing.py > gpurun_out/$TAG/formulation_timing.txt 2>&1 || echo "formulation timing failed"
 timeout -k 10 300 python3 tools/transition_any_timing.py > gpurun_out/$TAG/transition_any_timing.txt 2>&1 || echo "transition_any timing failed"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/transition_any_trace -- python3 tools/transition_any_timing.py > /dev/null 2>&1 && cp $(ls gpurun_out/$TAG/transition_any_trace/*/*_kernel_stats.csv | head -1) gpurun_out/$TAG/transition_any_kernel_stats.csv
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/default_trace -- python3 bench.py --no-cpu-baseline --no-api > gpurun_out/$TAG/default_bench_under_rocprof.json 2> gpurun_out/$TAG/default_trace.err || { echo "rocprof default bench failed"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/default_trace -- python3 bench.py --no-cpu-baseline --no-api --no-variants > gpurun_out/$TAG/default_bench_under_rocprof.json 2> gpurun_out/$TAG/default_trace.err || { echo "rocprof default bench failed"; exit 1; }
 cp $(ls gpurun_out/$TAG/default_trace/*/*_kernel_stats.csv | head -1) gpurun_out/$TAG/default_bench_kernel_stats.csv
 for w in config3 config3u config4 config5; do cp $(ls gpurun_out/$TAG/pmc/$w/trace/*/*_kernel_stats.csv | head -1) gpurun_out/$TAG/pmc_${w}_kernel_stats.csv; done
 fi

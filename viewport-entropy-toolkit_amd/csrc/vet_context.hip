@@ -69,6 +69,7 @@ void Tuning::from_environment() {
     lut_occ8 = env_int("VET_LUT_OCC8", 0, 1, -1);
     fused_narrow = env_int("VET_FUSED_NARROW", 0, 1, 1);
     narrow_deal = env_int("VET_NARROW_DEAL", 0, 1, 1);
+    if (const char* e = getenv("VET_LUT_TIMELINE")) lut_timeline = e;
     no_exact_rows = env_flag("VET_NO_EXACT_ROWS");
 }
 

@@ -107,6 +107,7 @@ struct Tuning {
     int lut_occ8 = -1;          // VET_LUT_OCC8 (fused table kernel: -1 by shape)
     int fused_narrow = 1;       // VET_FUSED_NARROW: 8-lane rows for fused rows of 65..96 entries
     int narrow_deal = 1;        // VET_NARROW_DEAL: class-dealt blocks for those 8-lane rows (0: plain order, round 4)
+    std::string lut_timeline;   // VET_LUT_TIMELINE=path (development builds only): per-workgroup wall-clock timeline of the fused table kernel
     int no_exact_rows = 0;      // VET_NO_EXACT_ROWS: the weights pass never builds the exact weight rows (as if they did not fit
                                 // the device): the precise sweep in weights-only mode serves — the fallback's test switch
     void from_environment();

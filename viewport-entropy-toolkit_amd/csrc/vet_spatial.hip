@@ -295,10 +295,19 @@ int launch_lut_fused(vet_plan* pl, const vet::SampleSrc& src, int U, int T, cons
     // batches (+1 %) or for frames without the set (config 2 +2 %)
     const bool occ8 = c->tune.lut_occ8 >= 0 ? c->tune.lut_occ8 != 0 : (F.gs_log2 == 3 && !d_videos && dedup);
 #if VET_STAGE_CYCLES
-    DevBuf dbg;                               // development builds: cycles per stage (thread 0 of every workgroup), synchronous
+    DevBuf dbg, tl;                           // development builds: cycles per stage (thread 0 of every workgroup), synchronous
     HIP_TRY(dbg.alloc(64));
     HIP_TRY(hipMemsetAsync(dbg.p, 0, 64, s));
-    q.dbg = (unsigned long long*)dbg.p;
+    // VET_LUT_TIMELINE=path: per-workgroup wall-clock timeline instead of the (intrusive: waits on vmcnt) sub-stage counters
+    const char* tl_path = c->tune.lut_timeline.empty() ? nullptr : c->tune.lut_timeline.c_str();
+    const long n_items_tl = blocks;
+    if (tl_path) {
+        HIP_TRY(tl.alloc((size_t)n_items_tl * 48));
+        HIP_TRY(hipMemsetAsync(tl.p, 0, (size_t)n_items_tl * 48, s));
+        q.timeline = (unsigned long long*)tl.p;
+    } else {
+        q.dbg = (unsigned long long*)dbg.p;
+    }
 #endif
     {
         ProfScope ps(c, s, KID_SPATIAL);
@@ -307,6 +316,12 @@ int launch_lut_fused(vet_plan* pl, const vet::SampleSrc& src, int U, int T, cons
         HIP_TRY(hipGetLastError());
     }
 #if VET_STAGE_CYCLES
+    if (tl_path) {
+        std::vector<unsigned long long> h((size_t)n_items_tl * 6);
+        HIP_TRY(hipMemcpyAsync(h.data(), tl.p, h.size() * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (FILE* f = fopen(tl_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    } else
     {
         unsigned long long t[8] = {};
         HIP_TRY(hipMemcpyAsync(t, dbg.p, 64, hipMemcpyDeviceToHost, s));

@@ -226,6 +226,7 @@ struct LutParams {
     int dedup_min_users;          // DEDUP: videos of fewer users keep one row entry per user (as the launch without the set would:
                                   // an FP table's sums then do not depend on which videos share a batch)
     FusedLayout lay;              // FUSED: the launch's one "lattice" is the plan's fused table (n = lay.N slots)
+    unsigned long long* timeline; // development builds: [workgroup][6] wall clock (100 MHz) at entry / after the set / lists / walk / entropy, HW id
     unsigned long long* dbg;      // development builds (-DVET_STAGE_CYCLES=1): [4] cycles of thread 0 per stage, summed over the workgroups
     uint32_t* resolve;            // FP tables with marker entries: [0] = number of frames handed to the precise sweep
                                   // (a marked tile whose histogram stayed 0.0), then the frames; null otherwise
@@ -415,7 +416,13 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
     const int nf = (int)min((long)FPW, (long)T - f0);
 #if VET_STAGE_CYCLES
     unsigned long long tdbg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = p.dbg ? __builtin_readcyclecounter() : 0ull, tsub = tlast;
+    if (p.timeline && tid == 0) {
+        p.timeline[(long)blockIdx.x * 6 + 0] = wall_clock64();
+        p.timeline[(long)blockIdx.x * 6 + 5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) /* HW_ID */ |
+                                  ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) /* XCC_ID */ << 32);
+    }
     auto stage = [&](int i) {
+        if (p.timeline && tid == 0) p.timeline[(long)blockIdx.x * 6 + 1 + i] = wall_clock64();
         if (p.dbg) { const unsigned long long now = __builtin_readcyclecounter(); tdbg[i] += now - tlast; tlast = now; tsub = now; }
     };
     // parts of stage 0 (samples -> set): 4 LDS init + barriers, 5 sample loads (waited for), 6 record gathers (waited for),
@@ -746,6 +753,7 @@ __global__ __launch_bounds__(256, OCC8 ? 8 : (FPT ? 6 : 7)) void k_spatial_lut(c
         }
     }
 #if VET_STAGE_CYCLES
+    if (p.timeline && !p.dbg) stage(3);
     if (p.dbg) {
         stage(3);
         if (tid == 0)
