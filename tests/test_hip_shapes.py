@@ -285,6 +285,50 @@ def test_resident_result_stores_weights_for_wide_audiences(native, engine):
     plan.close()
 
 
+def _expected_table_rows(dirs):
+    """Rows of a weight table = classes of equal Vectors (value equality, -0.0 == 0.0), minus those whose mirror image
+    (x, -y, -z) belongs to a class that appears earlier (ensure_alias, vet_plan.hip)."""
+    d = np.ascontiguousarray(dirs.reshape(-1, 3) + 0.0)
+    first = {}
+    for i, row in enumerate(map(bytes, d.view(np.uint8).reshape(len(d), 24))):
+        first.setdefault(row, i)
+    m = np.ascontiguousarray(d * np.array([1.0, -1.0, -1.0]) + 0.0)
+    rows = 0
+    for key, i in first.items():
+        j = first.get(bytes(m[i].view(np.uint8)))
+        rows += 0 if (j is not None and j < i) else 1
+    return rows
+
+
+@pytest.mark.parametrize("W,H", [(100, 200), (6, 4), (200, 400), (640, 480)])
+def test_alias_table_built_on_the_device(native, engine, W, H):
+    """Round 6: the alias table (equal Vectors and mirror images share a table row) is built by device kernels instead of a
+    host hash map; the number of rows is the host rule's, and the gather over those rows agrees with the oracle."""
+    plan = plan_for(native, engine, [50], W=W, H=H, policy=1)
+    mu, mv = video(40, 25, seed=W)
+    res = plan.spatial(mu=mu, mv=mv)
+    assert plan.last_formulation(0) == "table"
+    assert plan.table_rows() == _expected_table_rows(vo.direction_grid(W, H))
+    ent, assign, _ = vo.spatial_series(mu, mv, W, H, [50])
+    assert np.array_equal(res["assign"], assign)
+    np.testing.assert_allclose(res["entropy"], ent, rtol=1e-8)
+    plan.close()
+    # no mirror sharing for plans that are not weighted tables of symmetric lattices: an explicit direction table with
+    # repeated and mirrored Vectors, -0.0 and +0.0 included
+    rng = np.random.default_rng(W)
+    base = vo.vector_from_spherical(np.round(rng.uniform(-180, 180, 300), 1), np.round(rng.uniform(-90, 90, 300), 1))
+    table = np.concatenate([base, base[::3] * np.array([1.0, -1.0, -1.0]), base[5:40], np.array([[1.0, -0.0, 0.0], [1.0, 0.0, -0.0]])])
+    plan = native.Plan(engine, [vo.fibonacci_lattice(50)], 120.0, 2.0, True, dir_table=table)
+    plan.set_table_policy(1)
+    ids = rng.integers(0, len(table), (12, 33)).astype(np.int32)
+    res = plan.spatial(ids=ids)
+    assert plan.table_rows() == _expected_table_rows(table)
+    for t in (0, 11):
+        e, _, _ = vo.spatial_entropy_frame(table[ids[t]], vo.fibonacci_lattice(50))
+        np.testing.assert_allclose(res["entropy"][t], e, rtol=1e-8)
+    plan.close()
+
+
 def _weights_fallback_worker(q, env):
     """Child process: weights output and fetched weight rows with / without the exact weight rows (knob read at engine creation)."""
     import os

@@ -192,7 +192,6 @@ struct vet_plan {
     uint32_t* d_alias = nullptr;   // [n_dirs] direction id -> table row (dense) | mirrored << 31 (ensure_alias)
     bool mirror = false;           // rows are shared between mirror-image directions
     uint2* d_dirrec = nullptr;     // [n_dirs] alias | nearest tile | lattice-0 row meta (k_dirrec), dedup-capable plans
-    std::vector<uint32_t> h_alias; // direction id -> canonical DIRECTION | mirrored << 31 (host only)
     int n_rows = 0;                // table rows in use = canonical directions, densely numbered (ensure_alias)
     int* d_canon = nullptr;        // [n_rows] table row -> its direction
     // fused table: one row per distinct direction over ALL lattices (vet_layout.hpp)

@@ -12,7 +12,6 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
-#include <unordered_map>
 
 namespace vh {
 
@@ -26,30 +25,11 @@ namespace vh {
 // alias[d] = row | mirrored << 31.
 int ensure_alias(vet_plan* pl) {
     if (pl->d_alias) return VET_OK;
-    const size_t D = (size_t)pl->n_dirs;
-    std::vector<double> raw(D * 3);
-    HIP_TRY(hipMemcpy(raw.data(), pl->d_dir_raw, D * 24, hipMemcpyDeviceToHost));
-    struct KeyHash {
-        size_t operator()(const std::array<uint64_t, 3>& k) const {
-            uint64_t h = k[0] * 0x9E3779B97F4A7C15ull;
-            h ^= (k[1] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2));
-            h ^= (k[2] * 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2));
-            return (size_t)h;
-        }
-    };
-    auto key_of = [](double x, double y, double z) {
-        std::array<uint64_t, 3> key;
-        const double v[3] = {x + 0.0, y + 0.0, z + 0.0};    // -0.0 -> +0.0
-        memcpy(key.data(), v, 24);
-        return key;
-    };
-    std::unordered_map<std::array<uint64_t, 3>, uint32_t, KeyHash> first;
-    first.reserve(D * 2);
-    std::vector<uint32_t> alias(D);
-    for (size_t d = 0; d < D; ++d)
-        alias[d] = first.emplace(key_of(raw[3 * d], raw[3 * d + 1], raw[3 * d + 2]), (uint32_t)d).first->second;
-    // mirror symmetry of every lattice, bit for bit on the unit vectors the kernels use
-    bool mirror = !pl->ctx->tune.no_mirror && pl->weighted;
+    vet_ctx* c = pl->ctx;
+    const long D = (long)pl->n_dirs;
+    if (D <= 0 || D >= (long)0x7FFFFFFF) return fail(VET_ERR_UNSUPPORTED, "direction table of %ld entries", D);
+    // mirror symmetry of every lattice, bit for bit on the unit vectors the kernels use (host: a few thousand values)
+    bool mirror = !c->tune.no_mirror && pl->weighted;
     for (const auto& L : pl->lat) {
         if (L.binned || L.h_unit.empty()) { mirror = false; break; }
         for (int i = 0; i < L.n && mirror; ++i) {
@@ -60,39 +40,54 @@ int ensure_alias(vet_plan* pl) {
         if (!mirror) break;
     }
     pl->mirror = mirror;
-    if (mirror) {
-        for (size_t d = 0; d < D; ++d) {
-            if (alias[d] != d) continue;                      // canonical rows only
-            const auto it = first.find(key_of(raw[3 * d], -raw[3 * d + 1], -raw[3 * d + 2]));
-            if (it != first.end() && it->second < d) alias[d] = it->second | 0x80000000u;
-        }
-        for (size_t d = 0; d < D; ++d) {                      // ids aliased to a mirrored row
-            const uint32_t a = alias[d];
-            if (!(a & 0x80000000u) && a != d) alias[d] = alias[a];
-        }
-    }
-    // table rows = canonical directions, densely numbered: a table holds n_rows + 1 rows instead of n_dirs + 1
-    // (100 x 200 grid: 9 951 of 20 301 — half the memory and half the build time; 3840 x 1920: 4.3 instead of 8.5 GB)
-    std::vector<int> canon;
-    std::vector<uint32_t> rowid(D, 0u), rowsel(D);
-    for (size_t d = 0; d < D; ++d)
-        if (alias[d] == (uint32_t)d) { rowid[d] = (uint32_t)canon.size(); canon.push_back((int)d); }
-    for (size_t d = 0; d < D; ++d) rowsel[d] = rowid[alias[d] & 0x7FFFFFFFu] | (alias[d] & 0x80000000u);
+    // the set, the classes, the mirror partners and the dense row numbering on the device (vet_plan_kernels.hpp: k_alias_*,
+    // k_canon_*), on the null stream: ensure_alias is synchronous, like the host map of rounds 2-5 it replaces
+    unsigned long long slots = 64;
+    while (slots < 2ull * (unsigned long long)D) slots <<= 1;
+    const int n_tiles = (int)((D + vet::CANON_TILE - 1) / vet::CANON_TILE);
+    DevBuf set, a0, a1, tcount, toff, rowid;
+    HIP_TRY(set.alloc(slots * 4));
+    HIP_TRY(a0.alloc((size_t)D * 4));
+    HIP_TRY(a1.alloc((size_t)D * 4));
+    HIP_TRY(tcount.alloc((size_t)n_tiles * 4));
+    HIP_TRY(toff.alloc(((size_t)n_tiles + 1) * 4));
+    HIP_TRY(rowid.alloc((size_t)D * 4));
     uint32_t* d_alias = nullptr;
     int* d_canon = nullptr;
-    hipError_t e = hipMalloc((void**)&d_alias, D * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_canon, canon.size() * sizeof(int));
-    if (e == hipSuccess) e = hipMemcpy(d_alias, rowsel.data(), D * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_canon, canon.data(), canon.size() * sizeof(int), hipMemcpyHostToDevice);
+    HIP_TRY(hipMemset(set.p, 0xFF, slots * 4));
+    const int grid = grid_for(D, 256, c->n_cu);
+    hipLaunchKernelGGL(vet::k_alias_insert, dim3(grid), dim3(256), 0, 0, (const double*)pl->d_dir_raw, D, (uint32_t*)set.p, slots - 1);
+    hipLaunchKernelGGL(vet::k_alias_lookup, dim3(grid), dim3(256), 0, 0, (const double*)pl->d_dir_raw, D, (const uint32_t*)set.p,
+                       slots - 1, (uint32_t*)a0.p);
+    const uint32_t* classes = (const uint32_t*)a0.p;
+    if (mirror) {
+        hipLaunchKernelGGL(vet::k_alias_mirror, dim3(grid), dim3(256), 0, 0, (const double*)pl->d_dir_raw, D, (const uint32_t*)set.p,
+                           slots - 1, (uint32_t*)a0.p);
+        hipLaunchKernelGGL(vet::k_alias_resolve, dim3(grid), dim3(256), 0, 0, (const uint32_t*)a0.p, D, (uint32_t*)a1.p);
+        classes = (const uint32_t*)a1.p;
+    }
+    hipLaunchKernelGGL(vet::k_canon_count, dim3(n_tiles), dim3(256), 0, 0, classes, D, (uint32_t*)tcount.p);
+    hipLaunchKernelGGL(vet::k_canon_scan, dim3(1), dim3(1024), 0, 0, (const uint32_t*)tcount.p, n_tiles, (uint32_t*)toff.p);
+    HIP_TRY(hipGetLastError());
+    uint32_t n_rows = 0;
+    HIP_TRY(hipMemcpy(&n_rows, (const uint32_t*)toff.p + n_tiles, 4, hipMemcpyDeviceToHost));
+    if (n_rows == 0) return fail(VET_ERR_DEVICE, "alias table: no canonical direction");
+    hipError_t e = hipMalloc((void**)&d_alias, (size_t)D * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_canon, (size_t)n_rows * sizeof(int));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(vet::k_canon_fill, dim3(n_tiles), dim3(256), 0, 0, classes, D, (const uint32_t*)toff.p, d_canon, (uint32_t*)rowid.p);
+        hipLaunchKernelGGL(vet::k_alias_rows, dim3(grid), dim3(256), 0, 0, classes, D, (const uint32_t*)rowid.p, d_alias);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();           // complete before the temporaries go and before any stream reads the tables
     if (e != hipSuccess) {
         if (d_alias) (void)hipFree(d_alias);
         if (d_canon) (void)hipFree(d_canon);
-        return fail(VET_ERR_DEVICE, "alias table upload failed: %s", hipGetErrorString(e));
+        return fail(VET_ERR_DEVICE, "alias table build failed: %s", hipGetErrorString(e));
     }
     pl->d_alias = d_alias;
     pl->d_canon = d_canon;
-    pl->n_rows = (int)canon.size();
-    pl->h_alias = std::move(alias);
+    pl->n_rows = (int)n_rows;
     return VET_OK;
 }
 
