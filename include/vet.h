@@ -46,6 +46,14 @@ extern "C" {
                            (+ vet_plan_set_raw_weights); batch descriptors in an event-guarded ring;
                            0.1.4.1: vet_device_pci_bus_id */
 #define VET_STREAM_LEGACY ((void *)1) /* == hipStreamLegacy: the null stream with legacy ordering */
+/* Policy 0 of vet_plan_set_table_policy: a weighted call gathers from the direction weight table iff it holds at least this
+ * many samples per direction of the plan's direction table.  Measured (profiles/r06/first_call.txt, grid_sensitivity.txt):
+ * building a direction's row costs what the sweep spends on ~20 samples; with the alias table built on the device the table's
+ * FIRST call costs at most 1 ms more than the sweep's on 100x200 / 200x400 grids and 27 % more on 3840x1920, and every later
+ * call of the plan is 3.7-10x cheaper than the sweep — at 2 samples per direction the table has paid for itself by the
+ * plan's second (large grids) to tenth (config-2-sized videos) call.  Rounds 1-5 used 8: the alias table was a host hash map
+ * then, which made a first call 1.5 s on a 3840x1920 grid. */
+#define VET_TABLE_SAMPLES_PER_DIRECTION 2
 
 enum {
     VET_OK = 0,
@@ -158,7 +166,7 @@ int64_t vet_plan_n_dirs(const vet_plan *plan);
  * integer formulation; `precise` keeps the exact key set, and `ftable` keeps every in-FoV tile without an FP32
  * value as a marker entry and hands the frames those markers decide to `precise` inside the same call.
  * Which formulation a call uses is a pure function of the plan and the call's shape, never of the
- * plan's history: policy 0 = table iff the call (or batch) holds >= 8 samples per direction of the
+ * plan's history: policy 0 = table iff the call (or batch) holds >= VET_TABLE_SAMPLES_PER_DIRECTION samples per direction of the
  * plan's direction table, +1 = table whenever it is inside the contract and fits, -1 = never table.
  * vet_plan_table_stride: row length of lattice k's table (of the plan's fused table — one row per direction over
  * all lattices — where that is the one in use), 0 = not built (yet), -1 = does not fit.

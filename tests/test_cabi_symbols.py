@@ -109,3 +109,9 @@ def test_environment_is_read_in_one_place_only():
             assert "VET_EXP" not in f.read_text(), f"{f.name} holds a timing-only experiment switch"
     product_flags = [line for line in mk.splitlines() if line.startswith("CXXFLAGS") and "VFLAGS" not in line]
     assert product_flags
+
+
+def test_policy_constant_matches_the_header():
+    from viewport_entropy_toolkit import _native
+    m = re.search(r"#define VET_TABLE_SAMPLES_PER_DIRECTION (\d+)", HEADER.read_text())
+    assert m and int(m.group(1)) == _native.TABLE_SAMPLES_PER_DIRECTION

@@ -75,7 +75,7 @@ def test_single_and_two_user_frames_over_all_directions(native, engine, tcs, fov
         res = plan.spatial(mu=mu, mv=mv)
         form = plan.last_formulation(0)
         # an integer formulation only where the plan's own bound puts it inside the contract
-        table_asked = policy > 0 or (policy == 0 and mu.size >= 8 * (W + 1) * (H + 1))
+        table_asked = policy > 0 or (policy == 0 and mu.size >= native.TABLE_SAMPLES_PER_DIRECTION * (W + 1) * (H + 1))
         want = ("table" if tab_bound <= 1e-7 else "ftable") if table_asked else ("sweep" if sweep_bound <= 1e-7 else "precise")
         assert form == want, (name, form, tab_bound, sweep_bound)
         ent, assign = oracle_for(tcs, fov, power, name, mu, mv)
@@ -135,7 +135,7 @@ def test_config4_shape(native, engine, policy):
     c = plan.spatial(mu=mu[:, perm], mv=mv[:, perm], want_assign=False)
     assert np.array_equal(c["entropy"], a["entropy"])
     d = plan.spatial(mu=mu[3333:7001], mv=mv[3333:7001], want_assign=False)
-    if policy != 0:                      # under policy 0 the shorter call is still a table call (8 x 20 301 samples)
+    if policy != 0:                      # under policy 0 the shorter call is still a table call (2 x 20 301 samples)
         assert np.array_equal(d["entropy"], a["entropy"][3333:7001])
     else:
         np.testing.assert_allclose(d["entropy"], a["entropy"][3333:7001], rtol=1e-8)

@@ -358,7 +358,7 @@ def test_config2_vs_oracle(native, engine, weighted, policy):
     plan = make_plan(native, engine, tcs, weighted=weighted, policy=policy)
     res = plan.spatial(mu=mu, mv=mv, want_weights=True)
     if weighted and policy == 0:
-        assert plan.last_formulation(0) == "table"      # 192 000 samples >= 8 x 20 301 directions
+        assert plan.last_formulation(0) == "table"      # 192 000 samples >= 2 x 20 301 directions
     ent, assign, weights = vo.spatial_series(mu, mv, 100, 200, tcs, use_weight_distribution=weighted,
                                              want_weights=True)
     rtol, atol = tol(1 if weighted and plan.last_formulation(0) == "table" else -1, 64)
@@ -553,7 +553,7 @@ def test_formulation_is_a_pure_function_of_the_call(native, engine):
     from viewport_entropy_toolkit import _synthetic
     plan = make_plan(native, engine, [50, 100], policy=0)
     small = _synthetic.random_walk_video(8, 300, base_seed=5)
-    big = _synthetic.random_walk_video(96, 2000, base_seed=6)          # 192 000 samples >= 8 x 20 301
+    big = _synthetic.random_walk_video(96, 2000, base_seed=6)          # 192 000 samples >= 2 x 20 301
     first = plan.spatial(mu=small[0], mv=small[1])["entropy"]
     assert plan.last_formulation(0) == "sweep" and plan.table_stride(0) == 0
     for v in range(80):

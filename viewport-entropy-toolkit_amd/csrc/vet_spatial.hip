@@ -146,9 +146,9 @@ int lut_frames_per_wg(int U, long total_frames, int n_cu, int n_sum) {
 // The formulation of a weighted call is a function of the plan, the call's shape and (table does not fit the free
 // device memory -> sweep) the memory left on the device — never of what the plan has processed before — and every
 // formulation adds in a fixed order, so the same input gives the same floats:
-//   table    policy +1, or policy 0 and the call holds at least 8 samples per direction of the table
-//            (building a row costs about what the sweep spends on 30 samples; a gathered sample is ~6x
-//            cheaper than a swept one), if the table fits and its error bound is inside the contract;
+//   table    policy +1, or policy 0 and the call holds at least VET_TABLE_SAMPLES_PER_DIRECTION samples per direction
+//            of the table (include/vet.h: building a row costs about what the sweep spends on 20 samples; a gathered
+//            sample is 4-10x cheaper than a swept one), if the table fits and its error bound is inside the contract;
 //   sweep    integer (2^-52) histogram, if its error bound is inside the contract;
 //   precise  FP64 histogram and exact weights otherwise.
 enum { F_TABLE = 0, F_SWEEP = 1, F_PRECISE = 2, F_FTABLE = 3 };
@@ -156,7 +156,7 @@ enum { F_TABLE = 0, F_SWEEP = 1, F_PRECISE = 2, F_FTABLE = 3 };
 bool table_requested(const vet_plan* pl, long samples, int U) {
     if (!pl->weighted || pl->table_policy < 0 || any_binned(pl) || U >= 65536) return false;
     if ((int)pl->lat.size() > vet::MAX_LATTICES) return false;
-    return pl->table_policy > 0 || samples >= 8 * (long)pl->n_dirs;
+    return pl->table_policy > 0 || samples >= (long)VET_TABLE_SAMPLES_PER_DIRECTION * (long)pl->n_dirs;
 }
 
 int sweep_shift(int U) {

@@ -209,6 +209,7 @@ def _ptr(a: Optional[np.ndarray]):
 
 
 VET_STREAM_LEGACY = 1
+TABLE_SAMPLES_PER_DIRECTION = 2      # include/vet.h: VET_TABLE_SAMPLES_PER_DIRECTION (policy 0: table iff samples >= this x directions)
 
 
 def _stream(handle):
