@@ -323,3 +323,17 @@ def test_bench_parity_reuses_the_cpu_baseline_sample():
     assert rec["parity"]["ok"] and rec["parity"]["frames"] > 64
     assert str(rec["parity"]["frames"]) in rec["cpu_baseline"]["sample"]
     assert rec["cpu_baseline"]["all_cores"]["cores"] > 1
+
+
+def test_bench_parity_violation_at_two_ranks():
+    """N > 1: every rank checks its own series and one all_reduce joins the verdicts; a violation on any rank fails the job
+    (no metric line, non-zero exit from the launcher)."""
+    env = dict(os.environ, VET_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload",
+                          "config2", "--no-cpu-baseline", "--no-api", "--no-variants", "--inject-fault", "entropy"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert "PARITY GATE FAILED" in out.stderr and '"ranks_failed": 2' in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

@@ -15,6 +15,3 @@ for f in 1 2 4; do
   VET_LUT_FPW=$f timeout -k 10 300 python3 tools/tail_probe.py >> $O/tail_probe.txt 2>&1
 done
 echo done
-# grid-stride form of the fused kernel (VET_LUT_PERSIST = resident workgroups per CU), same box
-echo "== persist A/B" > $O/persist_ab.txt
-bash tools/ab_env.sh "VET_LUT_PERSIST=0 VET_LUT_PERSIST=8 VET_LUT_PERSIST=7,VET_LUT_OCC8=0 VET_LUT_PERSIST=8,VET_LUT_FPW=1 VET_LUT_PERSIST=4" "config4 defaults" 2 >> $O/persist_ab.txt 2>&1
