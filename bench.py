@@ -206,15 +206,19 @@ def parity_gate(eng, mode, tcs, weighted, W, H, mu_h, mv_h, ent_dev, idx_dev, po
     outputs the cpu_baseline leg already computed (frames, entropy, indices); without it the port runs on `n_frames`
     frames here.  Replaces the per-frame loops of analyzers/spatial_entropy.py:107-164 / transition_entropy.py:107-175."""
     T = mu_h.shape[0]
+    if n_frames <= 0:                    # --parity-frames 0: EVERY frame of the timed video, on the box's CPU share
+        n_frames, port_out = T, None
     if port_out is None:
         from oracle import c_port
         c_port.load()
-        c_port.set_threads(1)
+        aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        c_port.set_threads(1 if n_frames <= 64 else min(16, aff))
         take = min(T, n_frames + (1 if mode == "transition" else 0))
         if mode == "spatial":
             p_ent, p_idx = c_port.spatial_series(mu_h[:take], mv_h[:take], W, H, tcs, use_weight_distribution=weighted)[:2]
         else:
             p_ent, p_idx = c_port.transition_series(mu_h[:take], mv_h[:take], W, H, tcs)
+        c_port.set_threads(1)
     else:
         _, p_ent, p_idx = port_out
     rows = len(p_ent)
@@ -285,7 +289,8 @@ def main():
                          "100x200 = 20 301 directions; its README example is 200x400)")
     ap.add_argument("--parity-frames", type=int, default=64,
                     help="frames of the timed video the parity gate checks against the C port when the cpu_baseline leg "
-                         "(whose larger sample it otherwise reuses) does not run")
+                         "(whose larger sample it otherwise reuses) does not run; 0 = EVERY frame of the timed video (OpenMP "
+                         "port on the box's CPU share: ~20 s at config 3)")
     ap.add_argument("--inject-fault", default="none", choices=["none", "assign", "entropy", "table"],
                     help="TEST HOOK of the parity gate: corrupt one nearest-tile word / one entropy value of the engine's "
                          "output after the timed region, or build the engine's plan on a wrong lattice; bench.py must exit non-zero")
