@@ -709,6 +709,35 @@ def main():
                     "sol_ms": {"gather_all_l2_hits": t_l2 * 1e3, "gather_all_infinity_cache": t_mall * 1e3,
                                "lds_atomics_conflict_free": t_lds * 1e3},
                     "frac_of_sol": max(t_l2, t_lds) / (avg_kernel_ms * 1e-3)}
+                # The path the kernel actually queues on (profiles/r06/config4_workgroup_timeline.txt): 128-byte
+                # line requests of a CU's L1 to the L2 — a row's weight and tile lines (6 B per entry + one partial line at the
+                # end of either array), one record line per sample, the sample stream and the assignment stores — against the
+                # L1's outstanding-miss capacity, 64 slots / 296 cycles measured miss latency (profiles/r02/config3_pmc_stalls.json)
+                present = float(np.count_nonzero(~np.isnan(mu_h) & ~np.isnan(mv_h))) * n_batch / launches_per_step
+                row_lines = entries * 6.0 / 128.0 + float(distinct.sum()) * n_batch / launches_per_step
+                lines = row_lines + present + present * 16.0 / 128.0 + present * 4.0 / 128.0
+                ceiling = 64.0 / 296.0
+                # measured L2 requests of the same kernel (TCC_REQ, tools/pmc3.sh), if the record is of these kernel sources
+                measured, m_src = None, None
+                qf = ROOT / "profiles" / "pmc_sq.json"
+                if qf.exists() and args.data == "random_walk" and (W, H) == (100, 200):
+                    try:
+                        rec = json.loads(qf.read_text()).get(args.workload, {})
+                        if rec.get("kernel_src_sha") == kernel_src_sha() and rec.get("TCC_REQ_sum"):
+                            measured = float(rec["TCC_REQ_sum"])
+                            m_src = {"file": "profiles/pmc_sq.json", "counter": "TCC_REQ_sum", "kernel_src_sha": rec["kernel_src_sha"]}
+                    except Exception:  # noqa: BLE001
+                        measured = None
+                used = measured if measured else lines
+                rate = used / (avg_kernel_ms * 1e-3 * clk * cu)
+                out["roofline"]["secondary"]["l1_miss_path"] = {
+                    "what": "128-byte line requests of the CUs' L1s per launch / kernel time, per clock and CU, against the L1's "
+                            "outstanding-miss capacity (64 slots / 296 cycles per miss); measured = TCC_REQ of a rocprofv3 --pmc pass "
+                            "on these kernel sources, modelled = row lines + one record line per sample + sample stream + stores",
+                    "line_requests_per_launch": {"measured": measured, "modelled": lines, "provenance": m_src},
+                    "row_lines_modelled": row_lines, "record_lines_modelled": present,
+                    "lines_per_clock_per_cu": rate, "ceiling_lines_per_clock_per_cu": ceiling, "frac_of_ceiling": rate / ceiling,
+                    "clock_assumed_hz": clk}
             else:
                 flop = 13.5 * sum(n_lat) * U * T * n_batch / launches_per_step
                 out["roofline"]["secondary"] = {

@@ -47,7 +47,7 @@ for w in config3 config4 config5 defaults; do bash tools/pmc_sq.sh $w $TAG/pmc_s
 # L2 requests of the fused kernels (config 4, reference defaults)
 for w in config4 defaults; do bash tools/pmc3.sh $w $TAG/pmc_stalls_$w > gpurun_out/$TAG/pmc3_$w.log 2>&1 && cp gpurun_out/$TAG/pmc_stalls_$w/summary.json gpurun_out/$TAG/${w}_pmc_stalls.json; done
 # SQ record bench.py's transition `secondary` block reads (sha-guarded like pmc_traffic.json)
-python3 tools/pmc_sq_record.py config5=gpurun_out/$TAG/config5_pmc_sq.json config4=gpurun_out/$TAG/config4_pmc_sq.json config3=gpurun_out/$TAG/config3_pmc_sq.json defaults=gpurun_out/$TAG/defaults_pmc_sq.json > /dev/null && cp profiles/pmc_sq.json gpurun_out/$TAG/pmc_sq.json
+python3 tools/pmc_sq_record.py config5=gpurun_out/$TAG/config5_pmc_sq.json config4=gpurun_out/$TAG/config4_pmc_sq.json+gpurun_out/$TAG/config4_pmc_stalls.json config3=gpurun_out/$TAG/config3_pmc_sq.json+gpurun_out/$TAG/config3_pmc_stalls.json defaults=gpurun_out/$TAG/defaults_pmc_sq.json+gpurun_out/$TAG/defaults_pmc_stalls.json > /dev/null && cp profiles/pmc_sq.json gpurun_out/$TAG/pmc_sq.json
 line config5_with_sq --workload config5 --steps 50 --no-cpu-baseline --no-api
 timeout -k 10 300 python3 tools/weights_pass_timing.py > gpurun_out/$TAG/weights_pass_timing.txt 2>&1 || echo "weights pass timing failed"
 fi
