@@ -27,7 +27,16 @@ def set_threads(n: int) -> None:
 
 def load(build: bool = True):
     if not LIB.exists() and build:
-        subprocess.run(["make", "-C", str(HERE)], check=True, capture_output=True)
+        # several ranks of one job may get here together (bench.py's parity gate at N > 1): one of them builds
+        import fcntl
+        (HERE / "_build").mkdir(exist_ok=True)
+        with open(HERE / "_build" / ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if not LIB.exists():
+                    subprocess.run(["make", "-C", str(HERE)], check=True, capture_output=True)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     lib = C.CDLL(str(LIB))
     lib.oracle_spatial.restype = C.c_int
     lib.oracle_transition.restype = C.c_int
