@@ -128,7 +128,7 @@ def cpu_baseline(mu, mv, tcs, mode, weighted, budget_s, W=100, H=200):
         return frames, dt, res
 
     frames, dt, res = timed(1, budget_s * 0.6)
-    out = {"value": frames * U / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+    out = {"value": frames * U / dt, "unit": "samples/s", "frames_per_s": frames / dt, "cores": 1, "kind": "port",
            "sample": f"first {frames} of {T} frames x {U} users of the same workload, "
                      f"oracle/vet_oracle.c (gcc -O2, scalar FP64), {dt:.1f} s",
            "host_cpus": os.cpu_count(), "cpu_model": _cpu_model(),
@@ -141,7 +141,7 @@ def cpu_baseline(mu, mv, tcs, mode, weighted, budget_s, W=100, H=200):
     for share in sorted({min(16, aff), aff}):
         if share > 1:
             f2, d2, _ = timed(share, budget_s * 0.2)
-            tried.append({"value": f2 * U / d2, "unit": "samples/s", "cores": share,
+            tried.append({"value": f2 * U / d2, "unit": "samples/s", "frames_per_s": f2 / d2, "cores": share,
                           "sample": f"first {f2} frames, OpenMP over "
                                     f"{'frames' if mode == 'spatial' else 'samples (nearest-tile sweep) and rows'}, {d2:.1f} s"})
     c_port.set_threads(1)
